@@ -1,26 +1,33 @@
 #!/usr/bin/env python
 """bench.py -- the self-play hot path on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: this process starts the N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): 4096 concurrent games per GPU,
-400 simulations per move, no net.  One STEP = one ply of every game slot = 4096 x (1 root expansion
-+ 400 simulations) through the fused HIP kernel (selection, move generation, expansion, backup, pi,
-sampling, end-of-ply rules, sample-log row), games restarting by themselves when they end.
-`value` is the whole-job node-expansion rate with the parity-pinned table evaluator (config 2a:
-p = 1/294, v = 0 -- what the reference computes with a stub model); the random-rollout variant (2b)
-and, when the weights file is present, the net variant (config 3) are timed in the same run and
-reported under "variants".  Games shard over ranks by game id (rank r plays ids r, r+N, ...); the only
-collective is the summary all-reduce after the timed region.
+Headline workload (BASELINE.json configs[1]): 4096 concurrent games per GPU, 400 simulations
+per move, no net.  One STEP = one ply of every game slot = 4096 x (1 root expansion + 400 simulations) through the
+fused HIP kernel (selection, move generation, expansion, backup, pi, sampling, end-of-ply rules, sample-log row),
+games restarting by themselves when they end.  `value` is the whole-job node-expansion rate with the parity-pinned
+table evaluator (config 2a: p = 1/294, v = 0 -- what the reference computes with a stub model).
+
+Every rank then runs config 3 (BASELINE.json configs[2]: the same 4096 games x 400 simulations with good_model.h5
+through the fused fp32-MFMA evaluator kernel, stepped path) in steady state with restarts and reports games/s,
+samples/s, node-expansions/s and the evaluator kernel's MFMA roofline under "config3".  On one GPU the other
+configurations (2b, kernel micro-benchmarks) are timed under "variants".  Rank 0 finally times the CPU baselines
+(the C oracle = "port", and the reference-shaped pure-Python mirror with its calibration against the reference) on
+the host cores actually available to the process.
+
+Games shard over ranks by game id (rank r plays ids r, r+N, ...); the only collective is the summary all-reduce
+after each timed region (RCCL; gloo when CCSP_BENCH_ONE_DEVICE=1 puts all ranks on one device for functional tests).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -29,6 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, 64 FLOP/clk/SIMD
+NET_FLOP_PER_EVAL = 6483264   # 3,241,632 MAC
+SEED = 20261003
 
 
 def alg_bytes_per_expansion(D, K):
@@ -37,35 +47,119 @@ def alg_bytes_per_expansion(D, K):
     return 20.0 * D * K + 56.0 * K + 24.0 * D + 3956.0
 
 
-def cpu_baseline(seconds=12.0, sims=400, plies=16):
-    """the CPU oracle (oracle/ccsp_oracle.c, `port`) on all host cores: every thread plays whole
-    searches (uniform evaluator, `plies` MCTS plies per game after the opening) until `seconds` elapse"""
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import oracle_ffi as orc
-    L = orc.lib()
-    cores = os.cpu_count() or 1
-    done = [0] * cores
-    games = [0] * cores
-    t_end = time.time() + seconds
+def structure_bytes_per_expansion(D, K):
+    """what the FUSED kernel's own data structures move per expansion: selection reads P, W, N of
+    every edge of the D nodes on the path (20 D K) and the chosen edge's child word and move (6 D); the leaf's
+    position is rebuilt from the last path node's record (32); the new node block is written once (40 + 26 K);
+    backup is a read-modify-write of N and W of the D path edges (24 D).  No planes, no policy row, no child
+    positions: config 2a never materialises them."""
+    return 20.0 * D * K + 26.0 * K + 30.0 * D + 72.0
 
-    def work(i):
-        g = i
-        while time.time() < t_end:
-            done[i] += L.orc_bench_plies(20261003, g, sims, 0, plies)
-            games[i] += 1
-            g += cores
-    t0 = time.time()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    dt = time.time() - t0
-    return dict(value=sum(done) / dt, unit='node-expansions/s', cores=cores, kind='port',
-                sample='%d host threads x oracle searches (400 sims, table evaluator p=1/294 v=0, %d MCTS plies per game), '
-                       '%d games, %.1f s' % (cores, plies, sum(games), dt))
 
+# ---- multi-GPU launcher ---------------------------------------------------------------------------------------------
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a torchrun around it: start the N rank processes from THIS process, which
+    never touches the GPU (no torch.cuda / libccsp call before or after), wait for them, pass rank 0's JSON line
+    through (the children inherit stdout) and exit non-zero if any rank fails."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:                          # one rank failed: the others would wait in a collective for ever
+                    q.terminate()
+    if rc:
+        sys.stderr.write('bench.py: a rank process failed (exit code %d)\n' % rc)
+    return rc
+
+
+# ---- CPU baselines (rank 0, after the GPU work) -----------------------------------------------------------------------
+
+def usable_cores():
+    """host cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
+    1-GPU job 16 of its 256 logical CPUs; os.cpu_count() would say 256)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+def _run_cpu_workers(kind, workers, seconds, sims, plies):
+    """`workers` processes of oracle/cpu_worker.py (one per core, games sharded by id -- the reference's own
+    multiprocessing.Pool scheme, train.py:73-86), all timing the same window; -> (expansions/s, games, seconds)"""
+    start_at = time.time() + 1.5 + 0.02 * workers        # interpreters start and import before the window opens
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_worker.py'), '--kind', kind, '--seconds', str(seconds),
+           '--sims', str(sims), '--plies', str(plies), '--stride', str(workers), '--start-at', repr(start_at)]
+    procs = [subprocess.Popen(cmd + ['--first', str(i)], stdout=subprocess.PIPE, text=True) for i in range(workers)]
+    done, games, t_end = 0, 0, start_at
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('cpu worker failed')
+        r = json.loads(out.strip().splitlines()[-1])
+        done += r['expansions']
+        games += r['games']
+        t_end = max(t_end, r['t_end'])
+    return done / (t_end - start_at), games, t_end - start_at
+
+
+def cpu_baseline(seconds=8.0, sims=400):
+    """The oracle timed on the host cores: form (2) the C restatement (`port`) -- one process, then one
+    process per usable core; form (1) the reference-shaped pure-Python mirror (oracle/pymirror.py) on all cores, with
+    the container calibration that turns it into an estimate of the reference itself."""
+    cores = usable_cores()
+    one, _, _ = _run_cpu_workers('c', 1, max(2.0, seconds / 3), sims, 16)
+    allc, games, dt = _run_cpu_workers('c', cores, seconds, sims, 16)
+    out = dict(value=allc, unit='node-expansions/s', cores=cores, kind='port',
+               sample='%d processes (one per usable core; os.cpu_count() = %d) x oracle searches: %d sims per move, table '
+                      'evaluator p=1/294 v=0, 16 MCTS plies per game, %d games, %.1f s' % (cores, os.cpu_count() or 0, sims, games, dt),
+               single_thread=one, scaling_factor=allc / one if one else None)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import pymirror
+        cal = pymirror.CALIBRATION
+        pm, g2, dt2 = _run_cpu_workers('py', cores, seconds, sims, 1)
+        out['reference_shaped_python'] = dict(
+            value=pm, unit='node-expansions/s', cores=cores, per_core=pm / cores, kind='port (reference-shaped mirror, oracle/pymirror.py)',
+            sample='%d processes x 1 searched ply (%d sims, uniform table evaluator) per game, %d games, %.1f s' % (cores, sims, g2, dt2),
+            calibration=cal, reference_estimate=pm / cal['mirror_py310_over_reference_py39'])
+    except Exception as ex:
+        out['reference_shaped_python'] = {'skipped': repr(ex)}
+    return out
+
+
+# ---- timed regions -------------------------------------------------------------------------------------------------
 
 def timed_plies(eng, evaluator, steps, torch):
-    """`steps` launches of the fused kernel, one ply each; returns (wall seconds, avg kernel ms by HIP events)"""
+    """`steps` plies of the fused path; returns (wall seconds, avg ms of one ply's launches by HIP events recorded on
+    the stream the kernels are launched on)"""
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize()
     t0 = time.time()
@@ -79,6 +173,68 @@ def timed_plies(eng, evaluator, steps, torch):
     return wall, float(np.mean(kms))
 
 
+def weights_path():
+    p = os.path.join(ROOT, 'tests', 'golden', 'good_model.h5')
+    return p if os.path.exists(p) else None
+
+
+def config3(args, torch, rank, world, local, barrier):
+    """config 3 on this rank: `games` slots x `sims` simulations with the net, auto-restart, steady state"""
+    from chinesecheckersagent_amd import selfplay as sp
+    from chinesecheckersagent_amd.engine import _stream_ptr
+    from chinesecheckersagent_amd import _lib
+    from chinesecheckersagent_amd.model import ResidualCNN
+    G, S = args.games, args.sims
+    w = weights_path()
+    model = ResidualCNN(device='cuda:%d' % local)
+    if w:
+        model.load_weights(w)
+    warm, timed = args.net_warmup_plies, args.net_plies
+    parts = 2 if (G >= 2048 and G % 2 == 0) else 1
+    total = warm + timed + 8
+    if parts > 1:
+        b = sp.PipelinedSelfPlay(model, n_slots=G, n_parts=parts, sims=S, seed=SEED, first_game=rank, game_stride=world,
+                                 max_games=G * 64, auto_restart=True, log_capacity=G * total, device=local)
+        counters = b.counters
+    else:
+        b = sp.BatchSelfPlay(model, n_slots=G, sims=S, seed=SEED, first_game=rank, game_stride=world, max_games=G * 64,
+                             auto_restart=True, log_capacity=G * total, device=local)
+        counters = b.eng.counters
+    for _ in range(warm):
+        b.play_ply()
+    barrier()
+    c0 = counters()
+    t0 = time.time()
+    for _ in range(timed):
+        b.play_ply()
+    barrier()
+    dt = time.time() - t0
+    c1 = counters()
+    b.close()
+    d = {k: c1[k] - c0[k] for k in c1}
+    # the dominant kernel alone: net_forward_kernel on the batch one launch of the stepped path carries, HIP events on
+    # the launching stream
+    n_pos = G // parts
+    x = torch.rand((n_pos, 343), device='cuda:%d' % local)
+    L = _lib.lib()
+    packed = model._ensure_packed()
+    p_out = torch.empty((n_pos, 294), dtype=torch.float64, device=x.device)
+    v_out = torch.empty(n_pos, dtype=torch.float32, device=x.device)
+    st = _stream_ptr()
+    for _ in range(5):
+        L.ccsp_net_forward(packed.data_ptr(), x.data_ptr(), n_pos, None, p_out.data_ptr(), v_out.data_ptr(), st)
+    iters = 50
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        L.ccsp_net_forward(packed.data_ptr(), x.data_ptr(), n_pos, None, p_out.data_ptr(), v_out.data_ptr(), st)
+    e.record()
+    torch.cuda.synchronize()
+    k_ms = a.elapsed_time(e) / iters
+    return d, dt, dict(n_pos=n_pos, k_ms=k_ms, parts=parts, weights=os.path.basename(w) if w else 'random-init',
+                       backend=model.backend, warm=warm, timed=timed)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -86,9 +242,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
     ap.add_argument('--sims', type=int, default=400)
-    ap.add_argument('--no-extras', action='store_true', help='skip variants / micro-benchmarks / cpu baseline')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-extras', action='store_true', help='headline region only: no config 3, variants, cpu baseline')
+    ap.add_argument('--no-net', action='store_true', help='skip config 3')
+    ap.add_argument('--net-warmup-plies', type=int, default=72, help='config 3: untimed plies (the first cohort of games spreads out)')
+    ap.add_argument('--net-plies', type=int, default=96, help='config 3: timed plies')
+    ap.add_argument('--cpu-seconds', type=float, default=8.0)
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))               # before anything touches the GPU
 
     import torch
     from chinesecheckersagent_amd import _lib, engine, summary
@@ -96,7 +258,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     _lib.require_gpu()                      # no CPU fallback: fail loudly
     # functional test hook for 1-GPU boxes: CCSP_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo for
     # the summary (RCCL refuses two ranks on one device).  Never set by the driver.
@@ -119,9 +281,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_run(d, hist, elapsed):
+        """max elapsed over ranks; summary all-reduce (the path's only collective); every rank's
+        expansions through an all-gather of one int64"""
+        if dist is None:
+            return d, hist, elapsed, [d['expansions']]
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tot, hist = summary.allreduce_summary(d, hist, dist, device=coll_dev)
+        mine = torch.tensor([d['expansions']], dtype=torch.int64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return tot, hist, float(t.item()), [int(x.item()) for x in every]
+
     G, S, K, W = args.games, args.sims, args.steps, args.warmup
-    total_plies = 6 + W + K
-    eng = engine.SelfPlayEngine(n_slots=G, sims=S, seed=20261003, first_game=rank, game_stride=world,
+    eng = engine.SelfPlayEngine(n_slots=G, sims=S, seed=SEED, first_game=rank, game_stride=world,
                                 max_games=G * 64, log_capacity=G * (W + K + 8), auto_restart=True, device=local)
     EV = _lib.EVAL_UNIFORM
     eng.play_plies(EV, 6)                   # the six random opening plies (selfplay.py:32-33), untimed
@@ -135,68 +309,144 @@ def main():
     elapsed = time.time() - t0
     c1 = eng.counters()
     d = {k: c1[k] - c0[k] for k in c1}
-    hist = eng.visit_histogram()
-    # max elapsed over ranks; summary all-reduce (the path's only collective)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    tot, hist, elapsed, per_rank = reduce_run(d, eng.visit_histogram(), elapsed)
+    if dist is not None:                    # launch time of the slowest rank
+        t = torch.tensor([kernel_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot, hist = summary.allreduce_summary(d, hist, dist, device=coll_dev)
-    else:
-        tot = d
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        kernel_ms = float(t.item())
 
-    D = d['sum_depth'] / max(d['sims'], 1)
-    Kc = d['sum_children'] / max(d['expansions'], 1)
-    exp_per_launch = d['expansions'] / K
-    bytes_per_launch = exp_per_launch * alg_bytes_per_expansion(D, Kc)
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None                       # HBM bytes per launch from committed rocprofv3 PMC passes (see profiles/traffic.json)
-    try:
-        tr = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))['fused_sims_kernel']
-        if G == 4096 and S == 400:
-            traffic = (2.0 * tr['fetch_size_kb'] + tr['write_size_kb']) * 1024.0
-    except Exception:
-        pass
-    value = tot['expansions'] / elapsed
-    games_done = tot['games_won'] + tot['games_discarded']
-    out = {
-        'metric': 'mcts_node_expansions_per_s (self-play, %d games x %d sims/move per GPU)' % (G, S),
-        'value': value, 'unit': 'node-expansions/s', 'n_gpus': world, 'steps': K, 'warmup': W,
-        'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'config 2a: %d concurrent games/GPU x %d sims/move, table evaluator p=1/294 v=0 (no net), '
-                               'fused HIP select/movegen/expand/backup kernel, games auto-restart' % (G, S),
-                   'games_per_gpu': G, 'sims': S, 'sharding': 'game id mod n_gpus'},
-        'games_per_s': games_done / elapsed, 'plies_per_s': tot['plies'] / elapsed,
-        'games_finished': games_done, 'games_won': tot['games_won'], 'samples_logged': tot['samples'],
-        'mean_depth': D, 'mean_children': Kc, 'errors': tot['errors'],
-        'target_node_expansions_per_s_per_gpu': 1e6,
-        'roofline': {'bound': 'hbm', 'kernel': 'fused_sims_kernel (one ply = begin + sims + end launches)', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                     'bytes_per_expansion': alg_bytes_per_expansion(D, Kc), 'expansions_per_launch': exp_per_launch,
-                     'avg_launch_ms': kernel_ms},
-    }
-    if not args.no_extras and world == 1:
+    out = None
+    if rank == 0:
+        D = tot['sum_depth'] / max(tot['sims'], 1)
+        Kc = tot['sum_children'] / max(tot['expansions'], 1)
+        exp_per_launch = tot['expansions'] / K / world          # per GPU and ply
+        alg = alg_bytes_per_expansion(D, Kc)
+        own = structure_bytes_per_expansion(D, Kc)
+        achieved = exp_per_launch * alg / (kernel_ms * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'kernel': 'fused_sims_kernel (one ply = begin + sims + end launches)',
+                'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                'algorithmic_model': 'SURVEY.md 8d: 20DK + 56K + 24D + 3956 bytes per expansion (charges planes, policy row and '
+                                     'child positions that the fused kernel of config 2a never materialises)',
+                'bytes_per_expansion': alg, 'expansions_per_launch': exp_per_launch, 'avg_launch_ms': kernel_ms,
+                'kernel_structure_bytes_per_expansion': own,
+                'hbm_frac_kernel_structures': exp_per_launch * own / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        try:                                 # PMC figures cannot be taken inside this process: static, from the committed passes
+            prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))['fused_sims_kernel']
+            if G == 4096 and S == 400:
+                traffic = 2.0 * prof['fetch_size_kb'] * 1024.0 + prof['write_size_kb'] * 1024.0
+                roof['traffic'] = traffic
+                roof['traffic_source'] = 'static: ' + prof['source']
+                roof['hbm_frac_counters'] = traffic / (prof['launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                if 'insts_valu' in prof:
+                    # issue model: a wave64 VALU instruction holds its SIMD-32 for 2 cycles (4 for f64), the CU's one
+                    # scalar unit issues one SALU instruction per cycle for all four SIMDs
+                    clk = prof.get('clock_ghz', 2.1) * 1e9
+                    t_valu = prof['insts_valu'] * 2.0 / (256 * 4) / clk
+                    t_salu = prof['insts_salu'] / 256.0 / clk
+                    roof['issue_model'] = {'bound': 'instruction issue', 'insts_valu': prof['insts_valu'], 'insts_salu': prof['insts_salu'],
+                                           'valu_ms_at_2_cycles': t_valu * 1e3, 'salu_ms_at_1_per_cu_cycle': t_salu * 1e3,
+                                           'launch_ms': prof['launch_ms'], 'frac_of_issue_limit': max(t_valu, t_salu) * 1e3 / prof['launch_ms'],
+                                           'source': 'static: ' + prof['source']}
+        except Exception:
+            pass
+        games_done = tot['games_won'] + tot['games_discarded']
+        out = {
+            'metric': 'mcts_node_expansions_per_s (self-play, %d games x %d sims/move per GPU)' % (G, S),
+            'value': tot['expansions'] / elapsed, 'unit': 'node-expansions/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'config 2a: %d concurrent games/GPU x %d sims/move, table evaluator p=1/294 v=0 (no net), '
+                                   'fused HIP select/movegen/expand/backup kernel, games auto-restart' % (G, S),
+                       'games_per_gpu': G, 'sims': S, 'sharding': 'game id mod n_gpus'},
+            'games_per_s': games_done / elapsed, 'plies_per_s': tot['plies'] / elapsed,
+            'games_finished': games_done, 'games_won': tot['games_won'], 'samples_logged': tot['samples'],
+            'mean_depth': D, 'mean_children': Kc, 'errors': tot['errors'],
+            'per_rank_expansions': per_rank, 'visit_histogram_sum': int(np.asarray(hist, dtype=np.uint64).sum()),
+            'target_node_expansions_per_s_per_gpu': 1e6,
+            'roofline': roof,
+        }
+    extras_wanted = not args.no_extras
+    if extras_wanted and world == 1:
         out['variants'] = extras(eng, G, S, torch, _lib, engine)
-        out['cpu_baseline'] = cpu_baseline(args.cpu_seconds, S)
-    else:
-        out['cpu_baseline'] = None
     eng.close()
+
+    # ---- config 3: the net workload, every rank ---------------------------------------------------------------------
+    if extras_wanted and not args.no_net:
+        try:
+            d3, dt3, info = config3(args, torch, rank, world, local, barrier)
+            tot3, _, dt3, per3 = reduce_run(d3, np.zeros(_lib.NUM_ACTIONS, dtype=np.uint64), dt3)
+            if rank == 0:
+                ex = tot3['expansions']
+                tf = info['n_pos'] * NET_FLOP_PER_EVAL / (info['k_ms'] * 1e-3) / 1e12
+                out['config3'] = {
+                    'workload': 'config 3: %d concurrent games/GPU x %d sims/move, %s through the fused fp32-MFMA evaluator kernel, '
+                                'stepped path (select kernel -> net -> expand/backup kernel per simulation, 25 steps per hipGraph, '
+                                '%d half-batches on their own streams), games auto-restart; %d plies timed after %d untimed'
+                                % (G, S, info['weights'], info['parts'], info['timed'], info['warm']),
+                    'games_per_s': (tot3['games_won'] + tot3['games_discarded']) / dt3, 'games_won_per_s': tot3['games_won'] / dt3,
+                    'games_finished': tot3['games_won'] + tot3['games_discarded'], 'games_won': tot3['games_won'],
+                    'samples_per_s': tot3['samples'] / dt3, 'node_expansions_per_s': ex / dt3, 'plies_per_s': tot3['plies'] / dt3,
+                    'ms_per_sim_step': dt3 / info['timed'] / (S + 1) * 1e3, 'net_tflops_end_to_end': ex * NET_FLOP_PER_EVAL / dt3 / 1e12 / world,
+                    'errors': tot3['errors'], 'per_rank_expansions': per3, 'precision': 'fp32', 'backend': info['backend'],
+                    'roofline': {'bound': 'mfma', 'dtype': 'fp32', 'kernel': 'net_forward_kernel', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS,
+                                 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                                 'flop_per_position': NET_FLOP_PER_EVAL, 'positions_per_launch': info['n_pos'], 'avg_launch_ms': info['k_ms']},
+                }
+        except Exception as ex:
+            if rank == 0:
+                out['config3'] = {'skipped': repr(ex)}
+            if dist is not None:
+                raise
+    if rank == 0:
+        out['cpu_baseline'] = cpu_baseline(args.cpu_seconds, S) if extras_wanted else None
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def s1_positions(n_distinct, torch, rules, _lib):
+    """SURVEY.md §8d micro-benchmark inputs, built with the product's own kernels: state i = Board() advanced by
+    i mod 64 plies of rule S1 (selfplay.py:83-104: a checker that can move, uniformly; then one of its destinations,
+    uniformly), every third state a B8 randomised board instead (board.py:61-85)."""
+    dev = 'cuda'
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED)
+    start = np.tile(np.array([42, 35, 43, 28, 36, 44, 6, 13, 5, 20, 12, 4], dtype=np.uint8), (n_distinct, 1))
+    st = rules.to_device_states(_lib.pack_states(start))
+    idx = torch.arange(n_distinct, device=dev)
+    want = idx % 64
+    player = torch.ones(n_distinct, dtype=torch.uint8, device=dev)
+    for ply in range(63):
+        moves, count, masks = rules.movegen(st, player)
+        can = masks != 0                                                     # [n, 6]: checkers with at least one move
+        r = torch.rand(n_distinct, generator=gen, device=dev)
+        which = (r * can.sum(1)).long().clamp(max=5)                         # the which-th checker that can move
+        cid = ((can.cumsum(1) - 1 == which[:, None]) & can).float().argmax(1)
+        mine = (moves[:, :, 0].long() == cid[:, None]) & (torch.arange(126, device=dev)[None, :] < count[:, None].long())
+        r2 = torch.rand(n_distinct, generator=gen, device=dev)
+        nth = (r2 * mine.sum(1)).long()
+        j = ((mine.cumsum(1) - 1 == nth[:, None]) & mine).float().argmax(1)
+        mv = moves[idx, j].contiguous()
+        nxt, winner, _ = rules.step(st, player, mv)
+        go = (want > ply) & (winner == 0) & (count > 0)
+        st = torch.where(go[:, None], nxt, st).contiguous()
+        player = torch.where(go, 3 - player, player).contiguous()
+    # every third state: a randomised board
+    rng = np.random.RandomState(1)
+    cells = np.argsort(rng.rand(n_distinct, 49), axis=1)[:, :12].astype(np.uint8)
+    rnd = rules.to_device_states(_lib.pack_states(cells))
+    st = torch.where((idx % 3 == 2)[:, None], rnd, st).contiguous()
+    return st, player
 
 
 def extras(eng, G, S, torch, _lib, engine):
-    """the other configurations of SURVEY.md §8d and the kernel micro-benchmarks, same run"""
+    """the other configurations of SURVEY.md §8d and the kernel micro-benchmarks, same run (one GPU)"""
     from chinesecheckersagent_amd import rules
     v = {}
     # config 2b: random-rollout value (BASELINE.json configs[1] wording; no reference counterpart)
-    e = engine.SelfPlayEngine(n_slots=G, sims=S, seed=20261003, max_games=G * 8, log_capacity=G * 16, auto_restart=True)
+    e = engine.SelfPlayEngine(n_slots=G, sims=S, seed=SEED, max_games=G * 8, log_capacity=G * 16, auto_restart=True)
     e.play_plies(_lib.EVAL_ROLLOUT, 6)
     e.play_plies(_lib.EVAL_ROLLOUT, 1)
     torch.cuda.synchronize()
@@ -206,9 +456,9 @@ def extras(eng, G, S, torch, _lib, engine):
     v['2b_rollout'] = {'node_expansions_per_s': (c1['expansions'] - c0['expansions']) / wall, 'ms_per_ply': kms,
                        'workload': '%d games x %d sims, v = random playout <= 64 plies, p = 1/294' % (G, S)}
     e.close()
-    # games/s with an evaluator under which games END in wins (the uniform one of 2a never wins: every game is discarded
+    # games/s with a TABLE evaluator under which games END in wins (the uniform one of 2a never wins: every game is discarded
     # by the no-progress rule): spec.forward_eval, parity-pinned like 2a; steady state with restarts
-    e = engine.SelfPlayEngine(n_slots=G, sims=S, seed=20261003, max_games=G * 64, log_capacity=G * 160, auto_restart=True)
+    e = engine.SelfPlayEngine(n_slots=G, sims=S, seed=SEED, max_games=G * 64, log_capacity=G * 160, auto_restart=True)
     e.play_plies(_lib.EVAL_FORWARD, 70)                  # past the first wave of finishing games
     torch.cuda.synchronize()
     c0 = e.counters()
@@ -223,21 +473,12 @@ def extras(eng, G, S, torch, _lib, engine):
                              'node_expansions_per_s': (c1['expansions'] - c0['expansions']) / wall,
                              'samples_per_s': (c1['samples'] - c0['samples']) / wall,
                              'workload': '%d games x %d sims, table evaluator spec.forward_eval (games end in wins), restarts, 70 plies timed' % (G, S)}
-    # config 3: policy/value net through PyTorch-ROCm (stepped path), if the weights fixture is there
-    try:
-        from chinesecheckersagent_amd import selfplay as sp
-        r = sp.bench_net_plies(G, S, plies=2)
-        if r:
-            v['3_net'] = r
-    except Exception as ex:                      # the net variant is optional in this round
-        v['3_net'] = {'skipped': repr(ex)}
-    # kernel micro-benchmarks: 2^23 states so the working set exceeds the 256 MiB Infinity Cache
+    # kernel micro-benchmarks: 2^23 states so the working set exceeds the 256 MiB Infinity Cache;
+    # 2^16 distinct positions of the prescribed distribution, tiled
     n = 1 << 23
-    rng = np.random.RandomState(1)
-    cells = np.argsort(rng.rand(1 << 16, 49), axis=1)[:, :12].astype(np.uint8)
-    cells = np.tile(cells, (n >> 16, 1))
-    player = torch.from_numpy((1 + (np.arange(n) & 1)).astype(np.uint8)).cuda()
-    sd = rules.to_device_states(_lib.pack_states(cells))
+    sd0, pl0 = s1_positions(1 << 16, torch, rules, _lib)
+    sd = sd0.repeat(n >> 16, 1).contiguous()
+    player = pl0.repeat(n >> 16).contiguous()
     moves, count, masks = rules.movegen(sd, player)
     kmean = float(count.float().mean())
     L = _lib.lib()
@@ -253,7 +494,8 @@ def extras(eng, G, S, torch, _lib, engine):
         return a.elapsed_time(b) / iters * 1e-3
     dt = t(lambda: L.ccsp_movegen(sd.data_ptr(), player.data_ptr(), n, moves.data_ptr(), count.data_ptr(), masks.data_ptr(), sp_))
     v['movegen_kernel'] = {'states_per_s': n / dt, 'mean_moves': kmean, 'alg_bytes_per_state': 80 + 2 * kmean,
-                           'achieved_GBps': n * (80 + 2 * kmean) / dt / 1e9, 'frac_of_hbm_peak': n * (80 + 2 * kmean) / dt / 1e9 / HBM_PEAK_GBPS}
+                           'achieved_GBps': n * (80 + 2 * kmean) / dt / 1e9, 'frac_of_hbm_peak': n * (80 + 2 * kmean) / dt / 1e9 / HBM_PEAK_GBPS,
+                           'inputs': 'SURVEY 8d: Board() advanced by i mod 64 S1 plies, every third a randomised board; 2^16 distinct, tiled to 2^23'}
     mv = moves[:, 0, :].contiguous()
     nxt = torch.empty_like(sd); w = torch.zeros(n, dtype=torch.uint8, device='cuda'); pr = torch.zeros((n, 2), dtype=torch.uint8, device='cuda')
     dt = t(lambda: L.ccsp_step(sd.data_ptr(), player.data_ptr(), mv.data_ptr(), n, nxt.data_ptr(), w.data_ptr(), pr.data_ptr(), sp_))
@@ -273,7 +515,7 @@ def extras(eng, G, S, torch, _lib, engine):
     del best, cnt, sd
     # ... and the greedy data generator: whole games, one sample row (32 B state + 16 B meta + 2352 B pi) per ply
     gs = 16384
-    e = engine.SelfPlayEngine(n_slots=gs, sims=1, seed=20261003, max_games=gs * 64, log_capacity=gs * 300, auto_restart=True,
+    e = engine.SelfPlayEngine(n_slots=gs, sims=1, seed=SEED, max_games=gs * 64, log_capacity=gs * 300, auto_restart=True,
                               greedy_data=True)
     e.play_plies(0, 32)
     torch.cuda.synchronize()

@@ -11,6 +11,23 @@ void ccsp_set_hip_error(hipError_t e, const char *what);
         if (e_ != hipSuccess) { ccsp_set_hip_error(e_, #expr); return CCSP_EHIP; } \
     } while (0)
 
+// device allocation: hipErrorOutOfMemory is reported as CCSP_ENOMEM, anything else as CCSP_EHIP
+int ccsp_alloc_status(hipError_t e, const char *what);
+#define CCSP_ALLOCCHK(expr)                                                   \
+    do {                                                                      \
+        const int rc_ = ccsp_alloc_status((expr), #expr);                     \
+        if (rc_ != CCSP_OK) return rc_;                                       \
+    } while (0)
+
+// a device buffer that is freed on every way out of a host function
+struct ccsp_devbuf {
+    void *p = nullptr;
+    ccsp_devbuf() = default;
+    ccsp_devbuf(const ccsp_devbuf &) = delete;
+    ccsp_devbuf &operator=(const ccsp_devbuf &) = delete;
+    ~ccsp_devbuf() { if (p) (void)hipFree(p); }
+};
+
 // the ray table lives in device global memory (constant data); kernels stage it into LDS
 static __device__ const ccsp_ray_table CCSP_RAYS_DEV = ccsp_make_rays();
 

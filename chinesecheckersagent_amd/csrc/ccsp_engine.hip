@@ -867,8 +867,8 @@ __device__ __forceinline__ void wave_greedy_ply(const Params &P, Lds &lds, Slot 
             }
         }
         tl.samples += (row < P.log_cap) ? 1ULL : 0ULL;
-        tl.errors += (row < P.log_cap) ? 0ULL : 1ULL;
         sl.n_hist += 1;
+        if (row >= P.log_cap) { sl.status = CCSP_ST_ERROR; slot_finish(P, lds, sl, CCSP_ST_ERROR, tl); return; }   // log full: see wave_finish_ply
     }
     const int r = cnt > 1 ? (int)ccsp_choice(ccsp_rng_from(sl.hgame, sl.ply, 0, 0, CCSP_P_GREEDY), (uint32_t)cnt) : 0;
     const int j = nth_set_bit(f_lo, f_hi, r);
@@ -970,9 +970,11 @@ __device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot 
         for (int i = lane; i < CCSP_NUM_ACTIONS; i += 64) dst[i] = lds.pi[i];
     }
     tl.samples += (row < P.log_cap) ? 1ULL : 0ULL;
-    tl.errors += (row < P.log_cap) ? 0ULL : 1ULL;
     sl.n_hist += 1;
     tl.mcts_plies += 1;
+    // the sample log is full: the row is lost, so the game must not be handed back as if it were whole (its rows are
+    // labelled by alternation from the first one, utils.py:64-72) -- it ends with status ERROR and counts as an error
+    if (row >= P.log_cap) { sl.status = CCSP_ST_ERROR; slot_finish(P, lds, sl, CCSP_ST_ERROR, tl); return; }
     if (!found) { sl.status = CCSP_ST_ERROR; tl.errors += 1; return; }
     if (P.arena) slot_after_move_arena(P, lds, sl, cid, cdest, tl);
     else slot_after_move(P, lds, sl, cid, cdest, tl);
@@ -1342,10 +1344,21 @@ struct ccsp_ctx {
         if (e_ != hipSuccess) { ccsp_set_hip_error(e_, #expr); if (err) *err = CCSP_EHIP; ccsp_destroy(ctx); return nullptr; } \
     } while (0)
 
+#define CTXALLOC(ptr, bytes)                                                  \
+    do {                                                                      \
+        const int rc_ = ccsp_alloc_status(hipMalloc((void **)(ptr), (bytes)), "hipMalloc(" #ptr ")"); \
+        if (rc_ != CCSP_OK) { if (err) *err = rc_; ccsp_destroy(ctx); return nullptr; } \
+    } while (0)
+
+// Every entry point runs on the context's own device, whatever the caller's current device is, and refuses a
+// stream that belongs to another device (a launch there would fail with an invalid resource handle).
+static int ctx_enter(const ccsp_ctx *ctx, void *stream);
+
 extern "C" {
 
 int ccsp_destroy(ccsp_ctx *ctx) {
     if (!ctx) return CCSP_OK;
+    (void)ctx_enter(ctx, nullptr);
     Params &P = ctx->P;
     void *ptrs[] = {P.slots, P.pend, P.pool, P.path, ctx->sqrt_tab, ctx->pow_tab, ctx->rcp_tab, P.counters, P.stepacc, P.visit_hist,
                     P.log_state, P.log_meta, P.log_pi, P.log_count, P.results, P.next_index};
@@ -1387,33 +1400,33 @@ ccsp_ctx *ccsp_create(const ccsp_config *cfg, int *err) {
     P.path_stride = (uint32_t)(cfg->sims + 2);
     ctx->pool_bytes = G * P.pool_stride;
     ctx->path_bytes = G * P.path_stride * sizeof(uint64_t);
-    CTXCHK(hipMalloc((void **)&P.slots, G * sizeof(SlotMem)));
-    CTXCHK(hipMalloc((void **)&P.pend, G * sizeof(Pending)));
-    CTXCHK(hipMalloc((void **)&P.pool, ctx->pool_bytes));
-    CTXCHK(hipMalloc((void **)&P.path, ctx->path_bytes));
-    CTXCHK(hipMalloc((void **)&P.counters, CCSP_CNT_COUNT * sizeof(unsigned long long)));
-    CTXCHK(hipMalloc((void **)&P.stepacc, G * 8 * sizeof(uint32_t)));
-    CTXCHK(hipMalloc((void **)&P.visit_hist, CCSP_NUM_ACTIONS * sizeof(unsigned long long)));
-    CTXCHK(hipMalloc((void **)&P.log_count, sizeof(unsigned long long)));
-    CTXCHK(hipMalloc((void **)&P.next_index, sizeof(unsigned long long)));
+    CTXALLOC(&P.slots, G * sizeof(SlotMem));
+    CTXALLOC(&P.pend, G * sizeof(Pending));
+    CTXALLOC(&P.pool, ctx->pool_bytes);
+    CTXALLOC(&P.path, ctx->path_bytes);
+    CTXALLOC(&P.counters, CCSP_CNT_COUNT * sizeof(unsigned long long));
+    CTXALLOC(&P.stepacc, G * 8 * sizeof(uint32_t));
+    CTXALLOC(&P.visit_hist, CCSP_NUM_ACTIONS * sizeof(unsigned long long));
+    CTXALLOC(&P.log_count, sizeof(unsigned long long));
+    CTXALLOC(&P.next_index, sizeof(unsigned long long));
     const uint64_t cap = P.log_cap ? P.log_cap : 1;
-    CTXCHK(hipMalloc((void **)&P.log_state, cap * sizeof(ccsp_state)));
-    CTXCHK(hipMalloc((void **)&P.log_meta, cap * sizeof(ccsp_sample_meta)));
-    CTXCHK(hipMalloc((void **)&P.log_pi, cap * CCSP_NUM_ACTIONS * sizeof(double)));
-    CTXCHK(hipMalloc((void **)&P.results, P.max_games * sizeof(ccsp_game_result)));
+    CTXALLOC(&P.log_state, cap * sizeof(ccsp_state));
+    CTXALLOC(&P.log_meta, cap * sizeof(ccsp_sample_meta));
+    CTXALLOC(&P.log_pi, cap * CCSP_NUM_ACTIONS * sizeof(double));
+    CTXALLOC(&P.results, P.max_games * sizeof(ccsp_game_result));
     // integer-indexed tables from the HOST's libm: sqrt(n) (MCTS.py:62) and n**100 (MCTS.py:132, tau = 0.01)
     const int nt = cfg->sims + 2;
     std::vector<double> sq(nt), pw(nt);
     for (int i = 0; i < nt; i++) { sq[i] = sqrt((double)i); pw[i] = pow((double)i, 1. / 0.01); }
-    CTXCHK(hipMalloc(&ctx->sqrt_tab, nt * sizeof(double)));
-    CTXCHK(hipMalloc(&ctx->pow_tab, nt * sizeof(double)));
+    CTXALLOC(&ctx->sqrt_tab, nt * sizeof(double));
+    CTXALLOC(&ctx->pow_tab, nt * sizeof(double));
     CTXCHK(hipMemcpy(ctx->sqrt_tab, sq.data(), nt * sizeof(double), hipMemcpyHostToDevice));
     CTXCHK(hipMemcpy(ctx->pow_tab, pw.data(), nt * sizeof(double), hipMemcpyHostToDevice));
     P.sqrt_tab = (const double *)ctx->sqrt_tab; P.pow_tab = (const double *)ctx->pow_tab;
     const int nr = nt > RCP_N ? nt : RCP_N;                // reciprocals by IEEE division on the host (pick_edge)
     std::vector<double> rc(nr);
     for (int i = 0; i < nr; i++) rc[i] = i ? 1.0 / (double)i : 0.0;
-    CTXCHK(hipMalloc(&ctx->rcp_tab, nr * sizeof(double)));
+    CTXALLOC(&ctx->rcp_tab, nr * sizeof(double));
     CTXCHK(hipMemcpy(ctx->rcp_tab, rc.data(), nr * sizeof(double), hipMemcpyHostToDevice));
     P.rcp_tab = (const double *)ctx->rcp_tab;
     if (ccsp_reset(ctx, nullptr) != CCSP_OK) { if (err) *err = CCSP_EHIP; ccsp_destroy(ctx); return nullptr; }
@@ -1425,7 +1438,7 @@ int ccsp_reset(ccsp_ctx *ctx, void *stream) {
     if (!ctx) return CCSP_EINVAL;
     Params &P = ctx->P;
     hipStream_t s = (hipStream_t)stream;
-    CCSP_HIPCHK(hipSetDevice(ctx->cfg.device));
+    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
     CCSP_HIPCHK(hipMemsetAsync(P.counters, 0, CCSP_CNT_COUNT * sizeof(unsigned long long), s));
     CCSP_HIPCHK(hipMemsetAsync(P.stepacc, 0, (size_t)P.n_slots * 8 * sizeof(uint32_t), s));
     CCSP_HIPCHK(hipMemsetAsync(P.visit_hist, 0, CCSP_NUM_ACTIONS * sizeof(unsigned long long), s));
@@ -1447,22 +1460,23 @@ int ccsp_set_positions(ccsp_ctx *ctx, const ccsp_state *states, const uint8_t *p
     const Params &P = ctx->P;
     hipStream_t s = (hipStream_t)stream;
     const size_t G = (size_t)P.n_slots;
-    void *d_states = nullptr, *d_player = nullptr, *d_game = nullptr, *d_ply = nullptr, *d_tau = nullptr;
-    CCSP_HIPCHK(hipMalloc(&d_states, G * sizeof(ccsp_state)));
-    CCSP_HIPCHK(hipMalloc(&d_player, G));
-    CCSP_HIPCHK(hipMalloc(&d_game, G * 8));
-    CCSP_HIPCHK(hipMalloc(&d_ply, G * 4));
-    CCSP_HIPCHK(hipMalloc(&d_tau, G));
-    CCSP_HIPCHK(hipMemcpy(d_states, states, G * sizeof(ccsp_state), hipMemcpyHostToDevice));
-    CCSP_HIPCHK(hipMemcpy(d_player, player, G, hipMemcpyHostToDevice));
-    CCSP_HIPCHK(hipMemcpy(d_game, game, G * 8, hipMemcpyHostToDevice));
-    CCSP_HIPCHK(hipMemcpy(d_ply, ply, G * 4, hipMemcpyHostToDevice));
-    CCSP_HIPCHK(hipMemcpy(d_tau, det_tau, G, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(set_positions_kernel, dim3(P.n_slots), dim3(64), 0, s, P, (const ccsp_state *)d_states,
-                       (const uint8_t *)d_player, (const uint64_t *)d_game, (const uint32_t *)d_ply, (const uint8_t *)d_tau);
+    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    // staging buffers are released on every way out (ccsp_devbuf), allocation failure is CCSP_ENOMEM
+    ccsp_devbuf d_states, d_player, d_game, d_ply, d_tau;
+    CCSP_ALLOCCHK(hipMalloc(&d_states.p, G * sizeof(ccsp_state)));
+    CCSP_ALLOCCHK(hipMalloc(&d_player.p, G));
+    CCSP_ALLOCCHK(hipMalloc(&d_game.p, G * 8));
+    CCSP_ALLOCCHK(hipMalloc(&d_ply.p, G * 4));
+    CCSP_ALLOCCHK(hipMalloc(&d_tau.p, G));
+    CCSP_HIPCHK(hipMemcpy(d_states.p, states, G * sizeof(ccsp_state), hipMemcpyHostToDevice));
+    CCSP_HIPCHK(hipMemcpy(d_player.p, player, G, hipMemcpyHostToDevice));
+    CCSP_HIPCHK(hipMemcpy(d_game.p, game, G * 8, hipMemcpyHostToDevice));
+    CCSP_HIPCHK(hipMemcpy(d_ply.p, ply, G * 4, hipMemcpyHostToDevice));
+    CCSP_HIPCHK(hipMemcpy(d_tau.p, det_tau, G, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(set_positions_kernel, dim3(P.n_slots), dim3(64), 0, s, P, (const ccsp_state *)d_states.p,
+                       (const uint8_t *)d_player.p, (const uint64_t *)d_game.p, (const uint32_t *)d_ply.p, (const uint8_t *)d_tau.p);
     CCSP_HIPCHK(hipGetLastError());
     CCSP_HIPCHK(hipStreamSynchronize(s));
-    (void)hipFree(d_states); (void)hipFree(d_player); (void)hipFree(d_game); (void)hipFree(d_ply); (void)hipFree(d_tau);
     ctx->phase = 0;
     ctx->opening_plies = -1;           // these positions are searched at once
     return CCSP_OK;
@@ -1471,6 +1485,7 @@ int ccsp_set_positions(ccsp_ctx *ctx, const ccsp_state *states, const uint8_t *p
 int ccsp_play_plies(ccsp_ctx *ctx, int evaluator, int n_plies, void *stream) {
     if (!ctx || n_plies < 0 || evaluator < 0 || evaluator > CCSP_EVAL_ROLLOUT) return CCSP_EINVAL;
     if (n_plies == 0) return CCSP_OK;
+    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
     if (ctx->P.gen) {                                       // greedy data generator: nothing to search
         hipLaunchKernelGGL(greedy_plies_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, n_plies);
         CCSP_HIPCHK(hipGetLastError());
@@ -1491,6 +1506,7 @@ int ccsp_play_plies(ccsp_ctx *ctx, int evaluator, int n_plies, void *stream) {
 
 int ccsp_ply_begin(ccsp_ctx *ctx, float *planes, void *stream) {
     if (!ctx || !planes) return CCSP_EINVAL;
+    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
     hipLaunchKernelGGL(ply_begin_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, planes);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 1;
@@ -1500,6 +1516,7 @@ int ccsp_ply_begin(ccsp_ctx *ctx, float *planes, void *stream) {
 int ccsp_root_expand(ccsp_ctx *ctx, const double *p, const float *v, void *stream) {
     if (!ctx || !p || !v) return CCSP_EINVAL;
     if (ctx->phase != 1) return CCSP_ESTATE;
+    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
     hipLaunchKernelGGL(root_expand_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 2;
@@ -1509,6 +1526,7 @@ int ccsp_root_expand(ccsp_ctx *ctx, const double *p, const float *v, void *strea
 int ccsp_select(ccsp_ctx *ctx, float *planes, void *stream) {
     if (!ctx || !planes) return CCSP_EINVAL;
     if (ctx->phase != 2) return CCSP_ESTATE;
+    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
     hipLaunchKernelGGL(select_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, planes);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 3;
@@ -1518,6 +1536,7 @@ int ccsp_select(ccsp_ctx *ctx, float *planes, void *stream) {
 int ccsp_expand_backup(ccsp_ctx *ctx, const double *p, const float *v, void *stream) {
     if (!ctx || !p || !v) return CCSP_EINVAL;
     if (ctx->phase != 3) return CCSP_ESTATE;
+    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
     hipLaunchKernelGGL(expand_backup_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 2;
@@ -1527,6 +1546,7 @@ int ccsp_expand_backup(ccsp_ctx *ctx, const double *p, const float *v, void *str
 int ccsp_ply_end(ccsp_ctx *ctx, void *stream) {
     if (!ctx) return CCSP_EINVAL;
     if (ctx->phase != 2 && ctx->phase != 1) return CCSP_ESTATE;
+    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
     hipLaunchKernelGGL(ply_end_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 0;
@@ -1538,6 +1558,7 @@ int ccsp_ply_end(ccsp_ctx *ctx, void *stream) {
 
 int ccsp_read_counters(ccsp_ctx *ctx, uint64_t *out /* [CCSP_CNT_COUNT] */) {
     if (!ctx || !out) return CCSP_EINVAL;
+    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
     CCSP_HIPCHK(hipDeviceSynchronize());
     CCSP_HIPCHK(hipMemcpy(out, ctx->P.counters, CCSP_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
     // plus what the stepped kernels have tallied per slot since the last ply_end
@@ -1552,6 +1573,7 @@ int ccsp_read_counters(ccsp_ctx *ctx, uint64_t *out /* [CCSP_CNT_COUNT] */) {
 
 int ccsp_read_visit_histogram(ccsp_ctx *ctx, uint64_t *out /* [294] */) {
     if (!ctx || !out) return CCSP_EINVAL;
+    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
     CCSP_HIPCHK(hipDeviceSynchronize());
     CCSP_HIPCHK(hipMemcpy(out, ctx->P.visit_hist, CCSP_NUM_ACTIONS * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CCSP_OK;
@@ -1559,6 +1581,7 @@ int ccsp_read_visit_histogram(ccsp_ctx *ctx, uint64_t *out /* [294] */) {
 
 int ccsp_read_slots(ccsp_ctx *ctx, uint8_t *status, uint32_t *ply, uint64_t *game, ccsp_state *state, uint8_t *player) {
     if (!ctx) return CCSP_EINVAL;
+    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
     CCSP_HIPCHK(hipDeviceSynchronize());
     const int G = ctx->P.n_slots;
     std::vector<SlotMem> h((size_t)G);
@@ -1575,6 +1598,7 @@ int ccsp_read_slots(ccsp_ctx *ctx, uint8_t *status, uint32_t *ply, uint64_t *gam
 
 int ccsp_log_size(ccsp_ctx *ctx, uint64_t *n) {
     if (!ctx || !n) return CCSP_EINVAL;
+    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
     CCSP_HIPCHK(hipDeviceSynchronize());
     unsigned long long c = 0;
     CCSP_HIPCHK(hipMemcpy(&c, ctx->P.log_count, sizeof c, hipMemcpyDeviceToHost));
@@ -1605,6 +1629,7 @@ int ccsp_read_log(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_state *state, 
 
 int ccsp_read_results(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_game_result *out) {
     if (!ctx || !out || first + n > ctx->P.max_games) return CCSP_EINVAL;
+    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
     CCSP_HIPCHK(hipDeviceSynchronize());
     if (n) CCSP_HIPCHK(hipMemcpy(out, ctx->P.results + first, n * sizeof(ccsp_game_result), hipMemcpyDeviceToHost));
     return CCSP_OK;
@@ -1613,6 +1638,7 @@ int ccsp_read_results(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_game_resul
 // root edges of a slot's current tree (valid after a ply was searched, until the next one starts)
 int ccsp_read_root(ccsp_ctx *ctx, int slot, int *k_out, uint32_t *N, double *W, double *Pr, uint16_t *mv) {
     if (!ctx || slot < 0 || slot >= ctx->P.n_slots || !k_out) return CCSP_EINVAL;
+    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
     CCSP_HIPCHK(hipDeviceSynchronize());
     std::vector<uint8_t> blk(MAX_BLOCK_BYTES);
     CCSP_HIPCHK(hipMemcpy(blk.data(), ctx->P.pool + (uint64_t)slot * ctx->P.pool_stride, MAX_BLOCK_BYTES, hipMemcpyDeviceToHost));
@@ -1649,6 +1675,7 @@ static void digest_block(const uint8_t *pool, uint32_t off, uint64_t &h, uint64_
 
 int ccsp_debug_tree_digest(ccsp_ctx *ctx, int slot, uint64_t *digest, uint64_t *nodes, uint64_t *edges) {
     if (!ctx || slot < 0 || slot >= ctx->P.n_slots || !digest || !nodes || !edges) return CCSP_EINVAL;
+    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
     CCSP_HIPCHK(hipDeviceSynchronize());
     std::vector<uint8_t> pool(ctx->P.pool_stride);
     CCSP_HIPCHK(hipMemcpy(pool.data(), ctx->P.pool + (uint64_t)slot * ctx->P.pool_stride, ctx->P.pool_stride, hipMemcpyDeviceToHost));
@@ -1658,3 +1685,13 @@ int ccsp_debug_tree_digest(ccsp_ctx *ctx, int slot, uint64_t *digest, uint64_t *
 }
 
 }  // extern "C"
+
+static int ctx_enter(const ccsp_ctx *ctx, void *stream) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->cfg.device) CCSP_HIPCHK(hipSetDevice(ctx->cfg.device));
+    if (stream) {
+        hipDevice_t sd = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sd) == hipSuccess && (int)sd != ctx->cfg.device) return CCSP_EINVAL;
+    }
+    return CCSP_OK;
+}

@@ -9,6 +9,13 @@ void ccsp_set_hip_error(hipError_t e, const char *what) {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
 }
 
+int ccsp_alloc_status(hipError_t e, const char *what) {
+    if (e == hipSuccess) return CCSP_OK;
+    ccsp_set_hip_error(e, what);
+    (void)hipGetLastError();                              // the failed allocation must not poison later calls
+    return e == hipErrorOutOfMemory ? CCSP_ENOMEM : CCSP_EHIP;
+}
+
 extern "C" {
 
 const char *ccsp_last_hip_error(void) { return g_err; }

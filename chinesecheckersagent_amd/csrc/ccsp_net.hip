@@ -510,11 +510,14 @@ int ccsp_net_pack(const float *plain, float *packed) {
 int ccsp_net_forward(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream) {
     if (n < 0 || (n > 0 && (!packed || !planes || !v))) return CCSP_EINVAL;
     if (n == 0) return CCSP_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the 133 KB dynamic-LDS opt-in is a per-device property of the kernel: once per device ordinal, not per process
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    CCSP_HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         CCSP_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(net_forward_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int grid = (n + NB - 1) / NB;
     hipLaunchKernelGGL(net_forward_kernel, dim3(grid), dim3(NTH), sizeof(Smem), (hipStream_t)stream, packed, planes, n, logits, p, v);

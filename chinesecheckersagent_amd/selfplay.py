@@ -140,10 +140,19 @@ class BatchSelfPlay(object):
                 break
         return self.collect()
 
+    def _check_log_complete(self):
+        """a full sample log drops rows (the engine ends such games with status ERROR and counts an error): games
+        with missing plies must never reach the training data, so collecting from such a run raises"""
+        c = self.eng.counters()
+        if c['errors']:
+            raise _lib.CcspError('%d engine errors (sample log full after %d of %d rows, or a game ended in ERROR): '
+                                 'raise log_capacity' % (c['errors'], self.eng.log_size(), self.eng.log_capacity))
+
     def collect(self):
         """per finished game, in game-id order: (play_history, p1_reward) or (None, None) -- the
         return value of selfplay() (selfplay.py:45-47, 72-80)"""
         e = self.eng
+        self._check_log_complete()
         st, meta, pi = e.log()
         res = e.results()
         order = np.lexsort((meta['ply'], meta['game']))
@@ -173,6 +182,7 @@ class BatchSelfPlay(object):
         (utils.log_to_train_data): (board_x [N,7,7,7] f64, pi_y [N,294] f64, v_y [N] int64) of the games won so far"""
         from . import utils
         e = self.eng
+        self._check_log_complete()
         st, meta, pi = e.log()
         return utils.log_to_train_data(st, meta, pi, e.results(), first_game=e.first_game, game_stride=e.game_stride,
                                        randomised=self.randomised)
@@ -188,14 +198,17 @@ class PipelinedSelfPlay(object):
     4096 games x 400 simulations with good_model.h5: 12.5 -> 13.4 M node-expansions/s with two parts (four are slower).
     Same interface as BatchSelfPlay (play_ply / run_to_completion / collect / close)."""
 
-    def __init__(self, model1, model2=None, n_slots=2, n_parts=2, first_game=0, game_stride=1, max_games=None, log_capacity=None, **kw):
+    def __init__(self, model1, model2=None, n_slots=2, n_parts=2, first_game=0, game_stride=1, max_games=None, log_capacity=None,
+                 auto_restart=False, **kw):
         import torch
-        assert n_slots % n_parts == 0 and (max_games is None or max_games == n_slots)
+        max_games = n_slots if max_games is None else max_games
+        # part i plays ids first_game + (i + k n_parts) game_stride: with restarts every part draws from its own id budget
+        assert n_slots % n_parts == 0 and max_games % n_parts == 0 and (auto_restart or max_games == n_slots)
         self.torch = torch
         self.n_parts, self.n_slots = n_parts, n_slots
         per = n_slots // n_parts
         self.parts = [BatchSelfPlay(model1, model2, n_slots=per, first_game=first_game + i * game_stride,
-                                    game_stride=game_stride * n_parts, max_games=per,
+                                    game_stride=game_stride * n_parts, max_games=max_games // n_parts, auto_restart=auto_restart,
                                     log_capacity=None if log_capacity is None else log_capacity // n_parts, **kw)
                       for i in range(n_parts)]
         self.streams = [torch.cuda.Stream() for _ in range(n_parts)]
@@ -228,7 +241,7 @@ class PipelinedSelfPlay(object):
 
     def collect(self):
         outs = [b.collect() for b in self.parts]
-        return [outs[j % self.n_parts][j // self.n_parts] for j in range(self.n_slots)]
+        return [outs[j % self.n_parts][j // self.n_parts] for j in range(sum(len(o) for o in outs))]
 
     def collect_train_data(self):
         """the parts' samples, concatenated (training order is shuffled anyway)"""

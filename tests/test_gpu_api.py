@@ -211,3 +211,54 @@ def test_collect_train_data_equals_object_path(golden_dir):
         wx, wp, wv = utils.convert_to_train_data(kept)
         assert len(wx) == len(bx) > 0
         assert (np.array(wx) == bx).all() and (np.array(wp) == py).all() and list(vy) == wv
+
+
+def test_collect_refuses_a_run_with_dropped_rows(golden_dir):
+    """a sample log that is too small: the games that lost a row end in ERROR and collect() / collect_train_data()
+    raise instead of handing back histories with missing plies (their labels alternate from the first row)"""
+    from chinesecheckersagent_amd import _lib, selfplay as sp
+    from chinesecheckersagent_amd.model import ResidualCNN
+    m = ResidualCNN()
+    m.load_weights(golden_dir + '/good_model.h5')
+    b = sp.BatchSelfPlay(m, n_slots=4, sims=8, seed=3, max_games=4, log_capacity=6)
+    for _ in range(9):
+        b.play_ply()
+    assert b.eng.counters()['errors'] > 0
+    with pytest.raises(_lib.CcspError, match='log'):
+        b.collect()
+    with pytest.raises(_lib.CcspError, match='log'):
+        b.collect_train_data()
+    b.close()
+
+
+def test_bench_launcher_world2_on_one_device(tmp_path):
+    """`python bench.py --gpus 2` as the driver starts it: the launcher spawns both ranks before anything touches the GPU;
+    CCSP_BENCH_ONE_DEVICE=1 puts both on cuda:0 with a gloo summary (RCCL refuses two ranks on one device).  Games shard
+    by id, so two ranks of 32 slots do exactly the work of one run of 64 slots while no game ends."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    common = ['--sims', '24', '--steps', '3', '--warmup', '1', '--net-warmup-plies', '7', '--net-plies', '2', '--cpu-seconds', '0.5']
+
+    def run(extra, **envx):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra + common, env=dict(env, **envx),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    two = run(['--gpus', '2', '--games', '32'], CCSP_BENCH_ONE_DEVICE='1')
+    one = run(['--gpus', '1', '--games', '64'])
+    assert two['n_gpus'] == 2 and one['n_gpus'] == 1
+    assert len(two['per_rank_expansions']) == 2 and sum(two['per_rank_expansions']) == round(two['value'] * two['ms_per_step'] * 3 / 1e3)
+    assert sum(two['per_rank_expansions']) == one['per_rank_expansions'][0]           # id-sharding: same games, same work
+    assert two['visit_histogram_sum'] == one['visit_histogram_sum']
+    for doc in (one, two):
+        assert doc['errors'] == 0 and doc['roofline']['frac'] > 0 and doc['cpu_baseline']['value'] > 0
+        assert doc['cpu_baseline']['reference_shaped_python']['value'] > 0
+        c3 = doc['config3']
+        assert 'skipped' not in c3 and c3['errors'] == 0 and c3['node_expansions_per_s'] > 0 and c3['roofline']['bound'] == 'mfma'
+    assert sum(two['config3']['per_rank_expansions']) == one['config3']['per_rank_expansions'][0]
+    assert 'variants' in one and 'variants' not in two

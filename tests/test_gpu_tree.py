@@ -267,10 +267,39 @@ def test_restart_budget_log_overflow_and_odd_sizes(eng):
     e = eng.SelfPlayEngine(n_slots=5, sims=4, seed=1, max_games=5, log_capacity=2)
     e.play_plies(_lib.EVAL_UNIFORM, 8)
     c = e.counters()
-    assert e.log_size() == 2 and c['errors'] == 5 * 2 - 2 and c['samples'] == 2
+    # the three games whose first row did not fit end in ERROR at once, the other two when their second row does not
+    assert e.log_size() == 2 and c['errors'] == 5 and c['samples'] == 2
+    assert (e.slots()['status'] == _lib.ST_ERROR).all() and (e.results()['status'] == _lib.ST_ERROR).all()
     e.close()
     with pytest.raises(_lib.CcspError):
         eng.SelfPlayEngine(n_slots=0, sims=4, seed=1)
+
+
+def test_c_abi_error_paths(eng):
+    """allocation failure is CCSP_ENOMEM (not a generic HIP error) and leaves the device usable; a stream of another
+    device / a context used while another device is current (single-GPU box: the current-device half only)"""
+    import ctypes as C
+    import torch
+    from chinesecheckersagent_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.Config(n_slots=4, sims=4, randomised=0, auto_restart=0, seed=1, first_game=0, game_stride=1, max_games=4,
+                      log_capacity=1 << 42, device=0, max_plies=0, mode=0, arena_det_tau=0, enforce_move_limit=0, greedy=0,
+                      stuck_limit=0, pad=0)                      # 2^42 rows x 2.4 KB of pi: cannot be allocated
+    err = C.c_int(0)
+    assert not L.ccsp_create(C.byref(cfg), C.byref(err)) and err.value == _lib.ENOMEM
+    with pytest.raises(_lib.CcspError, match='ENOMEM'):
+        eng.SelfPlayEngine(n_slots=4, sims=4, seed=1, max_games=4, log_capacity=1 << 42)
+    # ... and the next context works, set_positions included (its staging buffers are freed on every path)
+    e = eng.SelfPlayEngine(n_slots=4, sims=4, seed=1, max_games=4, log_capacity=64)
+    free0 = torch.cuda.mem_get_info()[0]
+    s = e.slots()
+    for _ in range(50):
+        e.set_positions(s['state'], s['player'], s['game'], np.full(4, 6, dtype=np.uint32), np.zeros(4, dtype=np.uint8))
+    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)     # nothing leaked by 50 calls
+    e.play_plies(_lib.EVAL_HASH, 1)
+    assert e.counters()['errors'] == 0 and e.log_size() == 4
+    assert L.ccsp_set_positions(e.ctx, None, None, None, None, None, None) == _lib.EINVAL
+    e.close()
 
 
 def test_full_size_invariants_and_oracle_sample(eng):

@@ -177,3 +177,33 @@ def test_vectorised_plane_encoder_and_log_conversion(golden_dir):
         wx, wp, wv = utils.convert_to_train_data(games)
         assert len(wx) == len(bx) > 0
         assert (np.array(wx) == bx).all() and (np.array(wp) == py).all() and list(vy) == wv and vy.dtype == np.int64
+
+
+def test_bench_launcher_starts_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` (how the driver starts it: no torchrun around it) must start its two rank processes
+    itself; in this container they have no GPU, so each must stop at require_gpu() -- no CPU fallback -- and the
+    launcher must hand the failure on as a non-zero exit code, printing no result line"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: covered by the -m gpu launcher test')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--games', '8', '--sims', '4', '--steps', '1',
+                        '--warmup', '0', '--no-extras'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ''
+    assert 'no HIP device visible' in r.stderr and 'a rank process failed' in r.stderr
+
+
+def test_usable_cores_and_cpu_baseline_workers():
+    """bench.py's CPU-baseline leg: core count from affinity / cgroup quota, and the worker processes of both oracle forms"""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
+    rate, games, dt = bench._run_cpu_workers('c', 2, 0.5, 16, 2)
+    assert rate > 0 and games >= 2
+    rate, games, dt = bench._run_cpu_workers('py', 1, 0.2, 8, 1)
+    assert rate > 0 and games >= 1
