@@ -29,8 +29,12 @@ constexpr int ROWS = NB * 25;            // 200
 constexpr int MT = 13;                   // 16-row tiles (208 rows, 8 of them padding)
 constexpr int MTP = 14;                  // tiles allocated: waves that split 13 tiles unevenly compute one phantom tile
                                          // (rows 208..223) rather than branch around MFMAs
-constexpr int LDX = 68;                  // row stride of the 64-channel buffer (floats): 16-byte aligned, bank-spread
-constexpr int LDY = 36;                  // row stride of the 32-channel buffers
+#ifndef CCSP_NET_LDX
+#define CCSP_NET_LDX 68
+#define CCSP_NET_LDY 36
+#endif
+constexpr int LDX = CCSP_NET_LDX;        // row stride of the 64-channel buffer (floats): 16-byte aligned, bank-spread
+constexpr int LDY = CCSP_NET_LDY;        // row stride of the 32-channel buffers
 constexpr int LDI = 12;                  // input planes: 7 channels + zeros; 12 spreads eight consecutive cells over all banks
 constexpr int NPOL = 294, NPOL_PAD = 304;
 
@@ -203,6 +207,9 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     }
     __syncthreads();
     NET_STAMP(0);
+#ifdef CCSP_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) net_stamps[60] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- stem: 3x3 valid, K = 9 taps x 8 -> 5 k-blocks of 2 taps (10th tap = zero weights) -----------
     {
@@ -446,6 +453,9 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
         }
     }
     NET_STAMP(31);
+#ifdef CCSP_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) net_stamps[61] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // pack one GEMM weight matrix W[K][N] (row-major, K x N valid, zero padded) into [nt][kb][lane][j]

@@ -134,35 +134,48 @@ def log_to_train_data(states, meta, pi, results, first_game=0, game_stride=1, ra
     return board_x, np.asarray(pi, dtype=np.float64)[sel], v_y
 
 
+def _records_of(boards):
+    """BoardView objects -> their 32-byte records as one structured array (None if some object is not a BoardView)"""
+    from ._lib import STATE_DTYPE
+    if not all(hasattr(b, 'pos12') and hasattr(b, 'last4') for b in boards):
+        return None
+    rec = np.zeros(len(boards), dtype=STATE_DTYPE)
+    rec['pos'] = np.array([b.pos12 for b in boards], dtype=np.uint8).reshape(-1, 2, NUM_CHECKERS)
+    rec['last'] = np.array([b.last4 for b in boards], dtype=np.uint8).reshape(-1, 4)
+    return rec
+
+
 def convert_to_train_data(self_play_games):
-    """utils.py:60-73: [(play_history, p1_reward)] -> (board_x, pi_y, v_y) python lists"""
-    board_x, pi_y, v_y = [], [], []
+    """[(play_history, p1_reward)] -> (board_x, pi_y, v_y) as python lists, the output contract of utils.py:60-73: row j
+    of a game is encoded for player one if j is even, player two otherwise, and carries the reward with alternating sign.
+    The planes of all rows come from ONE call of the vectorised encoder (states_to_model_input)."""
+    boards, pi_y, labels, v_y = [], [], [], []
     for history, reward in self_play_games:
-        curr_player = PLAYER_ONE
-        for board, pi in history:
-            board_x.append(to_model_input(board, curr_player))
-            pi_y.append(pi)
-            v_y.append(reward)
-            reward = -reward
-            curr_player = PLAYER_ONE + PLAYER_TWO - curr_player
+        n = len(history)
+        boards += [b for b, _ in history]
+        pi_y += [pi for _, pi in history]
+        labels += [PLAYER_ONE if j % 2 == 0 else PLAYER_TWO for j in range(n)]
+        v_y += [reward if j % 2 == 0 else -reward for j in range(n)]
+    rec = _records_of(boards)
+    if rec is not None:
+        board_x = list(states_to_model_input(rec, np.array(labels, dtype=np.int64))) if len(boards) else []
+    else:                                              # foreign Board-like objects (e.g. the reference's own Board)
+        board_x = [to_model_input(b, p) for b, p in zip(boards, labels)]
     return board_x, pi_y, v_y
 
 
 def augment_train_data(board_x, pi_y, v_y):
-    """utils.py:77-97: append, for every sample, the planes mirrored along the other diagonal
-    (fliplr(rot90(.)) per channel).  As in the reference, pi is copied UN-mirrored (a reference quirk kept
-    for drop-in equality) and the same list objects are returned, extended in place."""
-    new_board_x, new_pi_y, new_v_y = [], [], []
-    for i in range(len(board_x)):
-        new_board = np.copy(board_x[i])
-        for j in range(new_board.shape[-1]):
-            new_board[:, :, j] = np.fliplr(np.rot90(new_board[:, :, j]))
-        new_board_x.append(new_board)
-        new_pi_y.append(np.copy(pi_y[i]))
-        new_v_y.append(v_y[i])
-    board_x += new_board_x
-    pi_y += new_pi_y
-    v_y += new_v_y
+    """The symmetry augmentation of utils.py:77-97 on whole arrays: every sample is appended once more with its planes
+    mirrored along the anti-diagonal (what fliplr(rot90(.)) does to each 7x7 channel: out[r, c] = in[6 - c, 6 - r]).
+    As in the reference pi is copied UN-mirrored (a reference quirk kept for drop-in equality) and the
+    same list objects are returned, extended in place."""
+    n = len(board_x)
+    if n:
+        x = np.asarray(board_x)
+        mirrored = x[:, ::-1, ::-1, :].transpose(0, 2, 1, 3)
+        board_x += list(np.ascontiguousarray(mirrored))
+        pi_y += [np.copy(p) for p in pi_y[:n]]
+        v_y += list(v_y[:n])
     return board_x, pi_y, v_y
 
 

@@ -163,6 +163,46 @@ def test_search_with_net_priors_matches_oracle(golden_dir):
         assert calls[0] >= nply * 40
 
 
+def test_config3_full_size_ply_matches_oracle(golden_dir):
+    """BASELINE.json config 3 at FULL size, exactly as bench.py runs it: 4096 slots x 400 simulations with good_model.h5,
+    PipelinedSelfPlay (two half-batches on two HIP streams, 25 simulation steps per captured hipGraph, fused evaluator
+    kernel on 2048 positions per launch).  One searched ply; 16 rows of the sample log spread over both halves are
+    re-searched by the CPU oracle calling back into the same evaluator one position at a time: pi must agree bit for
+    bit (400 simulations of float64 PUCT on float32-net priors, and the evaluator's independence of its batch)."""
+    import torch
+    from chinesecheckersagent_amd import selfplay as sp
+    from chinesecheckersagent_amd.model import ResidualCNN
+    m = ResidualCNN()
+    m.load_weights(golden_dir + '/good_model.h5')
+    seed, sims, G = 20261003, 400, 4096
+    b = sp.PipelinedSelfPlay(m, n_slots=G, n_parts=2, sims=sims, seed=seed, log_capacity=G * 4)
+    assert all(part.use_graph for part in b.parts)
+    for _ in range(7):
+        b.play_ply()
+    torch.cuda.synchronize()
+    assert all(part._graph is not None and part._unroll == 25 for part in b.parts)     # the captured-graph path really ran
+    c = b.counters()
+    assert c['errors'] == 0 and c['samples'] == G and c['sims'] == G * sims and c['expansions'] + c['terminal_sims'] == G * (sims + 1)
+    rows = []
+    for part in b.parts:
+        st, meta, pi = part.eng.log()
+        assert len(meta) == G // 2 and (meta['ply'] == 6).all()
+        assert np.abs(pi.sum(axis=1) - 1).max() < 1e-12
+        pick = np.argsort(meta['game'])[np.linspace(0, G // 2 - 1, 8).astype(int)]
+        rows += [(st[r], meta[r], pi[r]) for r in pick]
+    b.close()
+
+    def cb(planes_p, pos12_p, player, p_out, v_out, user):
+        x = np.ctypeslib.as_array(planes_p, shape=(343,)).astype(np.float32).reshape(1, 7, 7, 7)
+        p, v = m.evaluate_batch(torch.from_numpy(x).cuda())
+        np.ctypeslib.as_array(p_out, shape=(294,))[:] = p[0].cpu().numpy()
+        v_out[0] = float(v[0])
+    fn = orc.EVAL_FN(cb)
+    for st, meta, pi in rows:
+        o = orc.search(st['pos'].reshape(12), st['last'], int(meta['player']), seed, int(meta['game']), 6, sims, False, 4, fn=fn)
+        assert np.array_equal(pi, np.array(o.pi[:])), 'pi of game %d differs from the oracle at full size' % int(meta['game'])
+
+
 def test_pipelined_halves_equal_standalone_batches(golden_dir):
     """PipelinedSelfPlay (two half-batches on two HIP streams sharing one evaluator) returns, in game-id order, exactly
     what the two halves return when run alone one after the other"""

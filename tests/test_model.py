@@ -12,11 +12,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 
 LOGIT_TOL = 1e-5        # absolute, on logits in [-11, 17] (BASELINE.json north_star)
-# float32 evaluation (the reference's own Keras floatx) of this 30-layer net differs from ANY float64
-# evaluation by up to ~1.5e-5 on a handful of logits (7 float32 ulps at |logit| ~ 17): measured 8 of 75 264
-# logits above 1e-5, max 1.45e-5, mean 8e-7.  So: fp64 mode must meet 1e-5 outright (it meets 1e-9);
-# fp32 mode must have >= 99.9 % of logits within 1e-5 and all within 3e-5.
+# DEVIATION from north_star, stated in DESIGN.md section 5: a float32 evaluation (the reference's own Keras floatx) of
+# this 30-layer net differs from a float64 one by more than 1e-5 on a few logits in 10^4 whatever computes it -- the
+# float32 NumPy restatement (oracle/net_oracle.py, dtype=float32): 24 of 75 264 logits, max 2.1e-5; the fused HIP
+# kernel: 8 of 75 264, max 1.45e-5; mean 8e-7 for both.  So: fp64 mode meets 1e-5 outright (it meets 1e-9); fp32 modes
+# are held to >= 99.9 % of logits within 1e-5 and ALL within the cap below, and to being no further from the float64
+# vectors than the float32 restatement is (test_float32_distances).
 FP32_FRACTION, FP32_CAP = 0.999, 3e-5
+
+
+def _dist(a, b):
+    d = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))
+    return {'max': float(d.max()), 'mean': float(d.mean()), 'frac_within_1e-5': float((d < LOGIT_TOL).mean()), 'n_above_1e-5': int((d >= LOGIT_TOL).sum())}
 
 
 @pytest.fixture(scope='module')
@@ -152,3 +159,72 @@ def test_load_weights_by_layer_order_and_whole_model_files(net, golden_dir, tmp_
     c.load_weights(out_path)
     for pa, pc in zip(a.model.parameters(), c.model.parameters()):
         assert (pa == pc).all()
+
+
+def _fp32_restatement(golden_dir, net):
+    import net_oracle
+    from chinesecheckersagent_amd.model import read_keras_weights
+    w = read_keras_weights(golden_dir + '/good_model.h5')
+    return net_oracle.forward(w, net['planes'][:256], dtype=np.float32)
+
+
+def test_float32_distances(net, golden_dir):
+    """three-way distances on the 256 fixture positions (75 264 logits): float32 restatement vs float64 restatement, and
+    the product's float32 evaluation (CPU module here; the HIP kernel in the -m gpu twin) vs both"""
+    from chinesecheckersagent_amd.model import ResidualCNN
+    import torch
+    l32, v32 = _fp32_restatement(golden_dir, net)
+    assert l32.dtype == np.float32
+    ref64 = net['logits_good_model'][:256]
+    a = _dist(l32, ref64)
+    assert a['frac_within_1e-5'] >= FP32_FRACTION and a['max'] < FP32_CAP, a
+    m = ResidualCNN(device='cpu')
+    m.load_weights(golden_dir + '/good_model.h5')
+    lp, vp = m.predict_batch(torch.from_numpy(net['planes'][:256].astype(np.float32)))
+    b, c = _dist(lp.numpy(), ref64), _dist(lp.numpy(), l32)
+    assert b['max'] < FP32_CAP and c['max'] < FP32_CAP and b['mean'] < 2e-6 and c['mean'] < 2e-6, (b, c)
+    assert b['max'] <= 1.5 * a['max']            # the product is no further from float64 than float32 arithmetic itself is
+
+
+@pytest.mark.gpu
+def test_gpu_float32_distances(net, golden_dir):
+    """the fused HIP kernel against the float64 AND the float32 restatements, numbers written out for DESIGN.md"""
+    import json
+    import torch
+    from chinesecheckersagent_amd.model import ResidualCNN
+    l32, v32 = _fp32_restatement(golden_dir, net)
+    ref64 = net['logits_good_model'][:256]
+    m = ResidualCNN(device='cuda', backend='hip')
+    m.load_weights(golden_dir + '/good_model.h5')
+    lh, vh = m.predict_batch(torch.from_numpy(net['planes'][:256].astype(np.float32)).cuda())
+    lh, vh = lh.cpu().numpy(), vh.cpu().numpy()
+    doc = {'hip_fp32_vs_fp64_restatement': _dist(lh, ref64), 'hip_fp32_vs_fp32_restatement': _dist(lh, l32),
+           'fp32_restatement_vs_fp64_restatement': _dist(l32, ref64),
+           'v_hip_vs_fp64': _dist(vh, net['v_good_model'][:256]), 'north_star_tolerance': LOGIT_TOL, 'logits': int(lh.size)}
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    json.dump(doc, open(os.path.join(out, 'n1_parity.json'), 'w'), indent=1)
+    for k in ('hip_fp32_vs_fp64_restatement', 'hip_fp32_vs_fp32_restatement'):
+        assert doc[k]['frac_within_1e-5'] >= FP32_FRACTION and doc[k]['max'] < FP32_CAP and doc[k]['mean'] < 2e-6, doc
+    assert doc['v_hip_vs_fp64']['max'] < LOGIT_TOL
+    assert doc['hip_fp32_vs_fp64_restatement']['max'] <= 1.5 * doc['fp32_restatement_vs_fp64_restatement']['max']
+
+
+def test_against_keras_vectors_when_present(net, golden_dir):
+    """pins row N1 once somebody has run oracle/harness/gen_keras_net_golden.py where Keras exists"""
+    path = golden_dir + '/net_keras.npz'
+    if not os.path.exists(path):
+        pytest.skip('tests/golden/net_keras.npz absent: row N1 stays parity-unpinned at the Keras boundary '
+                    '(make it with oracle/harness/gen_keras_net_golden.py on a machine with Keras 2.1.6)')
+    import torch
+    from chinesecheckersagent_amd.model import ResidualCNN
+    k = np.load(path)
+    assert np.array_equal(k['planes'], net['planes'])
+    dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+    m = ResidualCNN(device=dev)
+    m.load_weights(golden_dir + '/good_model.h5')
+    lp, vp = m.predict_batch(torch.from_numpy(net['planes'][:256].astype(np.float32)).to(dev))
+    d = _dist(lp.cpu().numpy(), k['logits_good_model'][:256])
+    assert d['frac_within_1e-5'] >= FP32_FRACTION and d['max'] < FP32_CAP, d
+    assert _dist(net['logits_good_model'][:256], k['logits_good_model'][:256])['max'] < FP32_CAP     # the float64 oracle itself
+    assert np.abs(vp.cpu().numpy() - k['v_good_model'][:256]).max() < LOGIT_TOL

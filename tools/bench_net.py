@@ -2,6 +2,13 @@
 import sys, json, time
 sys.path.insert(0, '.')
 import numpy as np, torch
+import os, subprocess
+if len(sys.argv) > 1:            # extra hipcc flags (e.g. -DCCSP_NET_LDX=72 -DCCSP_NET_LDY=40): an experimental build beside the product's
+    from chinesecheckersagent_amd import _lib, build as B
+    so = os.path.join('chinesecheckersagent_amd', 'libccsp_exp.so')
+    subprocess.check_call(['hipcc'] + B.FLAGS + sys.argv[1:] + ['-o', so] + [os.path.join(B.CSRC, f) for f in B.SOURCES])
+    _lib.LIB_PATH = so
+    print('built', so, sys.argv[1:])
 from chinesecheckersagent_amd.model import ResidualCNN
 
 def t(fn, n=20):
@@ -9,7 +16,7 @@ def t(fn, n=20):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.time() - t0) / n * 1e3
 
-G = 4096
+G = 2048
 net = np.load('tests/golden/net.npz')
 x = torch.from_numpy(np.tile(net['planes'][:256].astype(np.float32), (G // 256, 1, 1, 1))).cuda()
 mh = ResidualCNN(backend='hip'); mh.load_weights('tests/golden/good_model.h5')

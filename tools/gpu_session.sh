@@ -1,0 +1,32 @@
+#!/bin/bash
+# One gpurun call = a list of steps, each under its own timeout; a step that is killed (exit >= 124) ends the session
+# (no further GPU step after a hang), an ordinary failure does not.   usage: bash tools/gpu_session.sh <tag> step...
+# steps: tests | bench | pmc[:what] | netexp:<flags,comma-separated> | stamps_net[:flags] | stamps | cmd:<shell command>
+tag=$1; shift
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+run() { # name seconds command...
+  local name=$1 secs=$2; shift 2
+  echo "=== $name ($(date +%T))"
+  timeout -k 10 "$secs" "$@" > gpurun_out/${tag}_$name.log 2>&1
+  local rc=$?
+  echo "=== $name rc=$rc"; tail -n 12 gpurun_out/${tag}_$name.log
+  if [ $rc -ge 124 ]; then echo "step $name was killed: session ends"; exit $rc; fi
+  return 0
+}
+for step in "$@"; do
+  case $step in
+    tests) run tests 900 python3 -m pytest tests -m gpu -x -q ;;
+    tests_all) run tests 900 python3 -m pytest tests -m gpu -q ;;
+    bench) run bench 600 python3 bench.py; grep '^{' gpurun_out/${tag}_bench.log > gpurun_out/${tag}_bench.json ;;
+    stats) rm -rf /tmp/st_$tag; run stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$tag -- python3 bench.py --steps 32 --cpu-seconds 1 --net-warmup-plies 8 --net-plies 4
+           f=$(find /tmp/st_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${tag}_bench_kernel_stats.csv ;;
+    pmc*) w=${step#pmc}; w=${w#:}; run pmc 1100 bash tools/pmc_round.sh $tag ${w:-all} ;;
+    netexp*) f=${step#netexp}; f=${f#:}; run netexp_$(echo "$f" | tr -c 'A-Za-z0-9\n' '_') 300 python3 tools/bench_net.py ${f//,/ } ;;
+    stamps_net*) f=${step#stamps_net}; f=${f#:}; run stamps_net_$(echo "$f" | tr -c 'A-Za-z0-9\n' '_') 300 python3 tools/stamps_net.py ${f//,/ } ;;
+    stamps) run stamps 300 python3 tools/stamps.py ;;
+    cmd:*) run cmd 600 bash -c "${step#cmd:}" ;;
+  esac
+done
+echo "=== session done"

@@ -1,0 +1,46 @@
+"""Development aid for the counter passes (tools/pmc_round.sh): a few launches of every kernel of the library on the
+benchmark's shapes -- move generation / step / encode / greedy on 2^22 positions of the SURVEY 8d distribution, the
+evaluator kernel on 2048 positions, four plies of config 2a (fused path), one ply of config 3 (stepped path)."""
+import sys
+sys.path.insert(0, '.')
+import torch
+import bench
+from chinesecheckersagent_amd import _lib, engine, rules, selfplay as sp
+from chinesecheckersagent_amd.model import ResidualCNN
+
+what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+L = _lib.lib()
+st = engine._stream_ptr()
+if what in ('all', 'rules'):
+    n = 1 << 22
+    sd0, pl0 = bench.s1_positions(1 << 16, torch, rules, _lib)
+    sd, player = sd0.repeat(n >> 16, 1).contiguous(), pl0.repeat(n >> 16).contiguous()
+    moves, count, masks = rules.movegen(sd, player)
+    for _ in range(3):
+        L.ccsp_movegen(sd.data_ptr(), player.data_ptr(), n, moves.data_ptr(), count.data_ptr(), masks.data_ptr(), st)
+    mv = moves[:, 0, :].contiguous()
+    nxt = torch.empty_like(sd); w = torch.zeros(n, dtype=torch.uint8, device='cuda'); pr = torch.zeros((n, 2), dtype=torch.uint8, device='cuda')
+    for _ in range(3):
+        L.ccsp_step(sd.data_ptr(), player.data_ptr(), mv.data_ptr(), n, nxt.data_ptr(), w.data_ptr(), pr.data_ptr(), st)
+    ne = 1 << 20
+    planes = torch.empty((ne, 343), dtype=torch.float32, device='cuda')
+    for _ in range(3):
+        L.ccsp_encode(sd.data_ptr(), player.data_ptr(), ne, planes.data_ptr(), st)
+    best = torch.zeros((ne, _lib.GREEDY_MAX, 2), dtype=torch.uint8, device='cuda'); cnt = torch.zeros(ne, dtype=torch.uint8, device='cuda')
+    for _ in range(3):
+        L.ccsp_greedy_best(sd.data_ptr(), player.data_ptr(), ne, best.data_ptr(), cnt.data_ptr(), st)
+    torch.cuda.synchronize()
+    print('rules kernels: n = %d, mean moves %.2f' % (n, float(count.float().mean())))
+if what in ('all', 'net'):
+    m = ResidualCNN(); m.load_weights('tests/golden/good_model.h5')
+    x = torch.rand((2048, 343), device='cuda')
+    for _ in range(8):
+        m.evaluate_batch(x)
+    torch.cuda.synchronize()
+if what in ('all', 'fused'):
+    e = engine.SelfPlayEngine(n_slots=4096, sims=400, seed=bench.SEED, max_games=4096 * 8, log_capacity=4096 * 16, auto_restart=True)
+    e.play_plies(_lib.EVAL_UNIFORM, 10)
+    torch.cuda.synchronize()
+    e.close()
+if what in ('all', 'stepped'):
+    print(sp.bench_net_plies(4096, 400, plies=1))

@@ -4,8 +4,8 @@ import os, subprocess, sys, ctypes as C
 sys.path.insert(0, '.')
 here = 'chinesecheckersagent_amd'
 so = os.path.join(here, 'libccsp_stamps.so')
-subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17', '-shared', '-DCCSP_STAMPS',
-                       '-o', so] + [os.path.join(here, 'csrc', f) for f in ('ccsp_rules_kernels.hip', 'ccsp_engine.hip', 'ccsp_net.hip', 'ccsp_host.hip')])
+subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17', '-shared', '-DCCSP_STAMPS'] + sys.argv[1:] +
+                      ['-o', so] + [os.path.join(here, 'csrc', f) for f in ('ccsp_rules_kernels.hip', 'ccsp_engine.hip', 'ccsp_net.hip', 'ccsp_host.hip')])
 import torch, numpy as np
 from chinesecheckersagent_amd import _lib
 _lib.LIB_PATH = so
@@ -40,3 +40,6 @@ print('3x3 per block: wave-0 barrier wait          %s' % w)
 
 print('block 4, 3x3: end of GEMM per wave (ticks after the layer started):', [t64[44 + w] - t64[2 + 3 * 4] for w in range(8)])
 print('HW_ID simd per wave:', [(t64[52 + w] >> 4) & 3 for w in range(8)], 'wave slot:', [t64[52 + w] & 15 for w in range(8)])
+
+rt = t64[61] - t64[60]
+print('in-kernel clock of workgroup 0: %d shader ticks / %d realtime ticks (100 MHz) = %.3f GHz' % (t64[31] - t64[0], rt, (t64[31] - t64[0]) / max(rt, 1) * 0.1))
