@@ -11,6 +11,13 @@
 //   value  1x1 64->1, flatten 25 -> dense 32 ReLU -> dense 1 tanh              (plain FMA, tiny)
 //   epilogue: p = float64 softmax(logits) (utils.softmax, utils.py:187-192), v float32
 //
+// Inner loops carry NO vector-ALU instruction besides the MFMAs: on gfx950 the fp32 MFMA shares the SIMD's fp32 lanes
+// with ordinary VALU work, and every v_cndmask / v_add between MFMAs was measured to cost 10-15 cycles of matrix pipe
+// (tools/probe/mfma_probe.hip: 99.7 % of the pipe on bare MFMAs, 67 % with one v_cndmask per MFMA).  Hence: the 3x3
+// layers read their input from a copy with a ZERO HALO (7x7 cells per position) instead of masking taps, weights come
+// through buffer loads whose addresses are scalar (SGPR offset + immediate), biases start the accumulators, and the
+// k-split's extra MFMAs sit behind one scalar branch per k-block.
+//
 // Packed weight order of a GEMM layer with K = 16*KB, N = 16*NT:  [nt][kb][lane][j]  =
 // W[k = 16 kb + 4 (lane >> 4) + j][n = 16 nt + (lane & 15)]  -- one 16-byte load per lane per 16 k.
 // Within a 16-k block the MFMA k-slot q = lane >> 4 therefore carries k = 4q + j in step j; A is read
@@ -71,11 +78,27 @@ constexpr Layout LAY = make_layout();
 constexpr int PLAIN_TOTAL = 4032 + 64 + 9 * (2048 + 32 + 9216 + 32 + 2048 + 64) + 1024 + 16 + 117600 + 294 + 64 + 1 + 800 + 32 + 32 + 1;
 static_assert(PLAIN_TOTAL == 244920, "249852 parameters minus the 4 x 1233 BatchNorm values folded away");
 
+constexpr int PADROWS = NB * 49;         // 3x3 input with a zero halo: position s, cell (r, c) of the 5x5 map at row s*49 + (r+1)*7 + (c+1)
+constexpr int INROWS = 448;              // staged input planes: 8 x 49 cells + what phantom rows / the zero-weight 10th tap reach
+
 struct Smem {
     float x[MTP * 16 * LDX];             // 64-channel trunk activations (60.9 KB)
-    float y1[MTP * 16 * LDY];            // 32-channel (32.3 KB); the stem's input planes and the policy conv output alias it
-    float y2[MTP * 16 * LDY];            // 32-channel (32.3 KB); logits / value scratch alias it
+    float y1[PADROWS * LDY];             // 32-channel 1x1 output = 3x3 input, zero halo (56.4 KB); the stem's input planes
+                                         // and the policy conv output alias it
+    float y2[MTP * 16 * LDY];            // 32-channel 3x3 output (32.3 KB); logits / value scratch alias it
     float part[2][4][256];               // partial sums of the k-split row tile 12 of the 32-column layers (8 KB)
+};
+static_assert(INROWS * LDI <= PADROWS * LDY, "the staged input planes alias y1");
+static_assert(sizeof(Smem) <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
+
+// the packed weights as a buffer resource: loads take a scalar byte offset (+ the lane's 16 bytes), no vector address math
+struct WBuf {
+    __amdgpu_buffer_rsrc_t r;
+    int voff;                            // lane * 16
+    __device__ __forceinline__ f32x4 load(int float_off) const {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, float_off * 4, 0));
+    }
 };
 
 __device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
@@ -88,30 +111,54 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
 
 // One GEMM layer for one wave: output tiles (mt0 .. mt0+NMT) x (one 16-column tile nt), K = 16*KB.
 // afrag(mt, kb, i) -> the lane's four A values of k-block kb for row tile mt (i = mt - mt0, a compile-time
-// slot for per-tile precomputed data);  epi(mt, acc) consumes a tile.
+// slot for per-tile precomputed data);  epi(mt, acc) consumes a tile (bias, residual, ReLU: the bias is added AFTER the
+// sum as Keras does -- starting the accumulator from it costs accuracy: 2.6e-5 instead of 1.5e-5 worst logit).  wbase = float offset of the layer's packed weights.
 // No tile is ever skipped: a wave whose share ends past tile 12 computes phantom rows (allocated, never read).
-template <int NMT, typename AFrag, typename Epi>
-__device__ __forceinline__ void gemm_tiles(const float *__restrict__ wpacked, int nt, int KB, int mt0,
-                                           AFrag afrag, Epi epi) {
-    const int lane = threadIdx.x & 63;
+// Register discipline of both loops (every index is static after unrolling): the A fragments of k-block kb live in
+// buffer kb & 1 and those of kb + 1 are read into the OTHER buffer, the weight ring slot refilled during k-block kb is the
+// one k-block kb - 1 used -- a load never targets a register an MFMA issued a moment ago still reads (the compiler would
+// otherwise pad such write-after-read hazards with s_nop).
+// A layer's FIRST weight k-blocks arrive in `pre` (NPRE of them, requested by the previous layer before its epilogue and
+// its barrier: an L2 round trip is a sixth of a 1x1 layer's MFMA time); next() is called once the last k-block's MFMAs
+// are issued and requests the following layer's.
+constexpr int NPREMAX = 3;
+template <int KB> struct Pre { static constexpr int N = KB < NPREMAX ? KB : NPREMAX; };
+template <int KBN>
+__device__ __forceinline__ void prefetch(const WBuf &wb, int wbase, int nt, f32x4 (&pre)[NPREMAX]) {
+#pragma unroll
+    for (int d = 0; d < Pre<KBN>::N; d++) pre[d] = wb.load(wbase + nt * KBN * 256 + d * 256);
+}
+
+template <int NMT, int KB, typename AFrag, typename Next, typename Epi>
+__device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, int mt0, f32x4 (&pre)[NPREMAX], AFrag afrag, Next next, Epi epi) {
+    constexpr int NPRE = Pre<KB>::N;
+    constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;                    // weight ring: PB - 1 k-blocks in flight (L2 latency)
     f32x4 acc[NMT];
 #pragma unroll
     for (int i = 0; i < NMT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 *bp = reinterpret_cast<const f32x4 *>(wpacked) + (size_t)nt * KB * 64 + lane;
-    f32x4 b = bp[0];
-    for (int kb = 0; kb < KB; kb++) {
-        const f32x4 bnext = (kb + 1 < KB) ? bp[(size_t)(kb + 1) * 64] : b;
-        f32x4 a[NMT];
+    const int w0 = wbase + nt * KB * 256;
+    f32x4 bq[PB];
 #pragma unroll
-        for (int i = 0; i < NMT; i++) a[i] = afrag(mt0 + i, kb, i);
+    for (int d = 0; d < NPRE; d++) bq[d] = pre[d];
+    f32x4 a[2][NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; i++) a[0][i] = afrag(mt0 + i, 0, i);
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);   // one k-block ahead (LDS latency)
+        }
+        if (kb + PB - 1 < KB && kb + PB - 1 >= NPRE) bq[(kb + PB - 1) % PB] = wb.load(w0 + (kb + PB - 1) * 256);
+        const f32x4 b = bq[kb % PB];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < NMT; i++)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], b[j], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb & 1][i][j], b[j], acc[i], 0, 0, 0);
         }
-        b = bnext;
     }
+    next();
 #pragma unroll
     for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i]);
 }
@@ -120,53 +167,67 @@ __device__ __forceinline__ void gemm_tiles(const float *__restrict__ wpacked, in
 // 32 slots duplicated, four phantom), a wave takes THREE full row tiles of its column tile and a quarter of the
 // k-range of row tile 12 (xmt) of the same column tile -- same weight stream, 3.25 jobs' worth of MFMAs instead of
 // 4.  The quarter's raw sums go to Smem::part and are added up in a fixed order after the layer's barrier.
-template <int NMT, typename AFrag, typename Epi>
-__device__ __forceinline__ void gemm_tiles_split(const float *__restrict__ wpacked, int nt, int KB, int mt0, int xmt, int kpart,
-                                                 AFrag afrag, Epi epi, float *part /* [256] of this (nt, kpart) */) {
+template <int NMT, int KB, typename AFrag, typename Next, typename Epi>
+__device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart, f32x4 (&pre)[NPREMAX],
+                                                 AFrag afrag, Next next, Epi epi, float *part /* [256] of this (nt, kpart) */) {
+    constexpr int NPRE = Pre<KB>::N;
+    constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;
     const int lane = threadIdx.x & 63;
     const int kb0 = (KB * kpart) >> 2, kb1 = (KB * (kpart + 1)) >> 2;
     f32x4 acc[NMT], accx = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NMT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 *bp = reinterpret_cast<const f32x4 *>(wpacked) + (size_t)nt * KB * 64 + lane;
-    // software pipeline: weights two k-blocks ahead (L2 latency), activations one k-block ahead (LDS latency)
-    f32x4 b0 = bp[0], b1 = bp[(size_t)(KB > 1 ? 1 : 0) * 64];
-    f32x4 a[NMT], ax;
+    const int w0 = wbase + nt * KB * 256;
+    f32x4 bq[PB];
 #pragma unroll
-    for (int i = 0; i < NMT; i++) a[i] = afrag(mt0 + i, 0, i);
-    ax = afrag(xmt, 0, NMT);
+    for (int d = 0; d < NPRE; d++) bq[d] = pre[d];
+    f32x4 a[2][NMT + 1];
+#pragma unroll
+    for (int i = 0; i < NMT; i++) a[0][i] = afrag(mt0 + i, 0, i);
+    a[0][NMT] = afrag(xmt, 0, NMT);
+#pragma unroll
     for (int kb = 0; kb < KB; kb++) {
-        const int k2 = kb + 2 < KB ? kb + 2 : KB - 1, k1 = kb + 1 < KB ? kb + 1 : KB - 1;
-        const f32x4 b2 = bp[(size_t)k2 * 64];
-        f32x4 an[NMT];
+        if (kb + 1 < KB) {
 #pragma unroll
-        for (int i = 0; i < NMT; i++) an[i] = afrag(mt0 + i, k1, i);
-        const f32x4 axn = afrag(xmt, k1, NMT);
-        const bool extra = (kb >= kb0) & (kb < kb1);                    // wave-uniform
+            for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
+            a[(kb + 1) & 1][NMT] = afrag(xmt, kb + 1, NMT);
+        }
+        if (kb + PB - 1 < KB && kb + PB - 1 >= NPRE) bq[(kb + PB - 1) % PB] = wb.load(w0 + (kb + PB - 1) * 256);
+        const f32x4 b = bq[kb % PB];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < NMT; i++)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], b0[j], acc[i], 0, 0, 0);
-            if (extra) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j], b0[j], accx, 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb & 1][i][j], b[j], acc[i], 0, 0, 0);
         }
+        if ((kb >= kb0) & (kb < kb1)) {                                 // wave-uniform: ONE scalar branch per k-block
 #pragma unroll
-        for (int i = 0; i < NMT; i++) a[i] = an[i];
-        ax = axn; b0 = b1; b1 = b2;
+            for (int j = 0; j < 4; j++) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb & 1][NMT][j], b[j], accx, 0, 0, 0);
+        }
     }
+    next();
 #pragma unroll
     for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i]);
     *reinterpret_cast<f32x4 *>(&part[lane * 4]) = accx;                 // D-fragment order: [lane][reg]
 }
 
+// ReLU as ONE instruction (v_med3_f32 v, 0, +inf): `v > 0 ? v : 0` costs a canonicalising v_max plus the v_max itself
+__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
+
 // after the barrier: row tile 12 of a 32-column layer = ((part0 + part1) + part2) + part3 + bias, ReLU
-__device__ __forceinline__ void reduce_split_tile(const float (*part)[4][256], const float *__restrict__ bias, float *y, int xmt) {
+template <bool PADDED>
+__device__ __forceinline__ void reduce_split_tile(const float (*part)[4][256], float bias /* of this thread's column, loaded before the layer */, float *y, int xmt) {
     const int tid = threadIdx.x;
     if (tid < 512) {
         const int nt = tid >> 8, e = tid & 255, lane = e >> 2, reg = e & 3;
         const int row = xmt * 16 + 4 * (lane >> 4) + reg, col = nt * 16 + (lane & 15);
-        const float v = ((part[nt][0][e] + part[nt][1][e]) + part[nt][2][e]) + part[nt][3][e] + bias[col];
-        y[row * LDY + col] = v > 0.f ? v : 0.f;
+        const float v = ((part[nt][0][e] + part[nt][1][e]) + part[nt][2][e]) + part[nt][3][e] + bias;
+        if (PADDED) {                                                       // 3x3 input: interior cell of the zero-halo copy
+            const int sp = row / 25, pos = row % 25;
+            if (row < ROWS) y[(sp * 49 + (pos / 5 + 1) * 7 + (pos % 5 + 1)) * LDY + col] = relu(v);
+        } else {
+            y[row * LDY + col] = relu(v);
+        }
     }
 }
 
@@ -199,10 +260,14 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     const long long s0 = (long long)blockIdx.x * NB;              // first position of this workgroup
     const int here = (int)((n - s0) < NB ? (n - s0) : NB);
 
-    // ---- input planes -> LDS [NB*49][8] (channel 7 = 0), aliasing y1 ---------------------------------
+    WBuf wb;
+    wb.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W), 0, LAY.total * 4, 0x00020000);
+    wb.voff = lane * 16;
+
+    // ---- input planes -> LDS [INROWS][LDI] (channels 7.. and the cells past the 8 positions = 0), aliasing y1 ----------
     float *in = S.y1;
-    for (int i = tid; i < NB * 49 * LDI; i += NTH) {
-        const int s = i / (49 * LDI), rem = i % (49 * LDI), cell = rem / LDI, ch = rem % LDI;
+    for (int i = tid; i < INROWS * LDI; i += NTH) {
+        const int cellg = i / LDI, ch = i % LDI, s = cellg / 49, cell = cellg % 49;
         in[i] = (ch < 7 && s < here) ? planes[(s0 + s) * 343 + cell * 7 + ch] : 0.0f;
     }
     __syncthreads();
@@ -211,94 +276,103 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     if (blockIdx.x == 0 && threadIdx.x == 0) net_stamps[60] = __builtin_amdgcn_s_memrealtime();
 #endif
 
+    const int nt2 = wave & 1, qr = wave >> 1, mt3 = 3 * qr;      // this wave's share of the 32-column layers (see below)
+    const int rcol = (tid >> 8) * 16 + (((tid & 255) >> 2) & 15);   // the column this thread finishes in reduce_split_tile
+    f32x4 pre[NPREMAX];                                          // the next layer's first weight k-blocks, in flight across barriers
+
     // ---- stem: 3x3 valid, K = 9 taps x 8 -> 5 k-blocks of 2 taps (10th tap = zero weights) -----------
+    // A row's nine taps are plain offsets from its top-left input cell (valid convolution); rows past the 200th and the
+    // zero-weight 10th tap read staged zeros.  No masks in the loop.
     {
-        auto afrag = [&](int mt, int kb, int) -> f32x4 {
-            const int row = mt * 16 + l15;
-            const int s = row / 25, pos = row % 25, r = pos / 5, c = pos % 5;
-            const int tap = kb * 2 + (q >> 1);
-            const int dr = tap / 3, dc = tap % 3;
-            const bool ok = (row < ROWS) & (tap < 9);
-            const int src = s * 49 + (r + dr) * 7 + (c + dc);       // padding rows / the 10th tap read on inside y1 and are zeroed
-            f32x4 a = *reinterpret_cast<const f32x4 *>(&in[src * LDI + (q & 1) * 4]);
-            if (!ok) a = f32x4{0.f, 0.f, 0.f, 0.f};
-            return a;
-        };
         const int nt = wave & 3, mt0 = (wave >> 2) * 7;        // 4 column tiles x 2 row halves (tile 13 phantom)
+        int sbase[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int row = (mt0 + i) * 16 + l15;
+            const int s = row / 25, pos = row % 25;
+            sbase[i] = (s * 49 + (pos / 5) * 7 + (pos % 5)) * LDI + (q & 1) * 4;
+        }
+        int tapoff[5];                                         // lane groups q = 0,1 carry tap 2 kb, q = 2,3 tap 2 kb + 1
+#pragma unroll
+        for (int kb = 0; kb < 5; kb++) {
+            const int tap = kb * 2 + (q >> 1);
+            tapoff[kb] = ((tap / 3) * 7 + tap % 3) * LDI;
+        }
+        auto afrag = [&](int, int kb, int i) -> f32x4 {
+            return *reinterpret_cast<const f32x4 *>(&in[sbase[i] + tapoff[kb]]);
+        };
         const float bv = W[LAY.stem_b + nt * 16 + l15];        // this lane's output column
         auto epi = [&](int mt, const f32x4 &acc) {
             for_each_out(mt, acc, [&](int row, int col, float v) {
-                const float o = v + bv;
-                S.x[row * LDX + nt * 16 + col] = o > 0.f ? o : 0.f;
+                S.x[row * LDX + nt * 16 + col] = relu(v + bv);
             });
         };
-        gemm_tiles<7>(W + LAY.stem_w, nt, 5, mt0, afrag, epi);
+        prefetch<5>(wb, LAY.stem_w, nt, pre);
+        gemm_tiles<7, 5>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
     }
+    __syncthreads();
+    // the staged planes are dead: y1 becomes the zero-halo 3x3 input (only interior cells are ever written again)
+    for (int i = tid * 4; i < PADROWS * LDY; i += NTH * 4) *reinterpret_cast<f32x4 *>(&S.y1[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     NET_STAMP(1);
 
-    // 3x3 layers: per row tile of this wave, once for all nine blocks: the row's address and which of the 9 taps stay
-    // inside its 5x5 map (slots 0-2: the wave's full tiles; slot 3: row tile 12, of which it computes a quarter of the
-    // k-range)
-    int rowaddr[4]; uint32_t tapmask[4];
-    {
-        const int mt0 = 3 * (wave >> 1);
+    // 32-column layers: a wave owns row tiles 3 qr .. 3 qr + 2 of column tile nt, and a quarter of tile 12's k-range.
+    // Per slot (0-2: the full tiles; 3: tile 12), once for all nine blocks:
+    //   a3[i]     element offset in y1 of the row's TOP-LEFT tap (zero-halo copy): tap (dr, dc) is + (dr*7 + dc) * LDY
+    //   prow[i][] element offsets in y1 of the four interior cells this lane's D fragment holds (1x1 epilogue -> 3x3 input)
+    int a3[4], prow[3][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = (i < 3 ? mt0 + i : 12) * 16 + l15;
-            const int pos = row % 25, r = pos / 5, c = pos % 5;
-            uint32_t m = 0;
-#pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const int dr = t / 3 - 1, dc = t % 3 - 1;
-                if ((r + dr >= 0) & (r + dr < 5) & (c + dc >= 0) & (c + dc < 5)) m |= 1u << t;
-            }
-            tapmask[i] = row < ROWS ? m : 0u;
-            rowaddr[i] = row * LDY + 4 * q;
-        }
+    for (int i = 0; i < 4; i++) {
+        int row = (i < 3 ? mt3 + i : 12) * 16 + l15;
+        if (row >= ROWS) row -= 25;                            // phantom rows of tile 12: any valid cell (results never read)
+        const int s = row / 25, pos = row % 25;
+        a3[i] = (s * 49 + (pos / 5) * 7 + (pos % 5)) * LDY + 4 * q;
     }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = (mt3 + i) * 16 + 4 * q + reg;      // < 192: always a real cell
+            const int s = row / 25, pos = row % 25;
+            prow[i][reg] = (s * 49 + (pos / 5 + 1) * 7 + (pos % 5 + 1)) * LDY;
+        }
 
     // ---- nine bottleneck residual blocks (model.py:120-145) ------------------------------------------
+    float rbias;
     for (int blk = 0; blk < 9; blk++) {
         {   // 1x1 64 -> 32: 2 column tiles x 4 row groups of three tiles + a quarter of tile 12's k-range each
-            const int nt = wave & 1, qr = wave >> 1, mt0 = 3 * qr;
             auto afrag = [&](int mt, int kb, int) -> f32x4 {
                 return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
             };
-            const float bv = W[LAY.l1_b[blk] + nt * 16 + l15];
+            const float bv = W[LAY.l1_b[blk] + nt2 * 16 + l15];
+            rbias = W[LAY.l1_b[blk] + rcol];
             auto epi = [&](int mt, const f32x4 &acc) {
-                for_each_out(mt, acc, [&](int row, int col, float v) {
-                    const float o = v + bv;
-                    S.y1[row * LDY + nt * 16 + col] = o > 0.f ? o : 0.f;
-                });
+                const int i = mt - mt3;
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++)
+                    S.y1[(i == 0 ? prow[0][reg] : (i == 1 ? prow[1][reg] : prow[2][reg])) + nt2 * 16 + l15] = relu(acc[reg] + bv);
             };
-            gemm_tiles_split<3>(W + LAY.l1_w[blk], nt, 4, mt0, 12, qr, afrag, epi, S.part[nt][qr]);
+            gemm_tiles_split<3, 4>(wb, LAY.l1_w[blk], nt2, mt3, 12, qr, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); }, epi,
+                                   S.part[nt2][qr]);
         }
         __syncthreads();
-        reduce_split_tile(S.part, W + LAY.l1_b[blk], S.y1, 12);
+        reduce_split_tile<true>(S.part, rbias, S.y1, 12);
         __syncthreads();
         NET_STAMP(2 + 3 * blk);
-        {   // 3x3 same 32 -> 32: k-block kb = tap (kb >> 1), channels 16 (kb & 1) ..; zero halo outside the 5x5 map
-            const int nt = wave & 1, qr = wave >> 1, mt0 = 3 * qr;
+        {   // 3x3 same 32 -> 32: k-block kb = tap (kb >> 1), channels 16 (kb & 1) ..; the halo supplies the zeros
             auto afrag = [&](int, int kb, int i) -> f32x4 {
-                const int tap = kb >> 1;                                        // wave-uniform
-                const int toff = ((tap / 3 - 1) * 5 + (tap % 3 - 1)) * LDY + (kb & 1) * 16;
-                const bool ok = (tapmask[i] >> tap) & 1u;
-                // a tap outside the 5x5 map still reads ITS OWN shifted address (inside Smem: the tail of x or y1's
-                // phantom rows) and is zeroed afterwards: a common dummy address would collide with the lane that
-                // owns those banks in every 8-lane group of the ds_read_b128
-                f32x4 a = *reinterpret_cast<const f32x4 *>(&S.y1[rowaddr[i] + toff]);
-                if (!ok) a = f32x4{0.f, 0.f, 0.f, 0.f};
-                return a;
+                const int tap = kb >> 1;                                        // compile-time after unrolling
+                return *reinterpret_cast<const f32x4 *>(&S.y1[a3[i] + ((tap / 3) * 7 + tap % 3) * LDY + (kb & 1) * 16]);
             };
-            const float bv = W[LAY.l2_b[blk] + nt * 16 + l15];
+            const float bv = W[LAY.l2_b[blk] + nt2 * 16 + l15];
+            rbias = W[LAY.l2_b[blk] + rcol];
             auto epi = [&](int mt, const f32x4 &acc) {
                 for_each_out(mt, acc, [&](int row, int col, float v) {
-                    const float o = v + bv;
-                    S.y2[row * LDY + nt * 16 + col] = o > 0.f ? o : 0.f;
+                    S.y2[row * LDY + nt2 * 16 + col] = relu(v + bv);
                 });
             };
-            gemm_tiles_split<3>(W + LAY.l2_w[blk], nt, 18, mt0, 12, qr, afrag, epi, S.part[nt][qr]);
+            gemm_tiles_split<3, 18>(wb, LAY.l2_w[blk], nt2, mt3, 12, qr, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
+                                    S.part[nt2][qr]);
             NET_STAMP(32 + blk);                             // diagnostic: wave 0 done with its share of the 3x3 layer
 #ifdef CCSP_STAMPS
             if (blockIdx.x == 0 && lane == 0 && blk == 4) {
@@ -308,10 +382,10 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
 #endif
         }
         __syncthreads();
-        reduce_split_tile(S.part, W + LAY.l2_b[blk], S.y2, 12);
+        reduce_split_tile<false>(S.part, rbias, S.y2, 12);
         __syncthreads();
         NET_STAMP(3 + 3 * blk);
-        {   // 1x1 32 -> 64 + residual: 4 column tiles x 2 row halves
+        {   // 1x1 32 -> 64 + residual: 4 column tiles x 2 row halves; the accumulators START from bias + block input
             const int nt = wave & 3, mt0 = (wave >> 2) * 7;
             auto afrag = [&](int mt, int kb, int) -> f32x4 {
                 return *reinterpret_cast<const f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + kb * 16 + 4 * q]);
@@ -320,11 +394,13 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
             auto epi = [&](int mt, const f32x4 &acc) {
                 for_each_out(mt, acc, [&](int row, int col, float v) {
                     float *px = &S.x[row * LDX + nt * 16 + col];
-                    const float o = v + bv + *px;                               // add([x, block_input]) then ReLU
-                    *px = o > 0.f ? o : 0.f;
+                    *px = relu(v + bv + *px);                                   // add([x, block_input]) then ReLU
                 });
             };
-            gemm_tiles<7>(W + LAY.l3_w[blk], nt, 2, mt0, afrag, epi);
+            gemm_tiles<7, 2>(wb, LAY.l3_w[blk], nt, mt0, pre, afrag, [&]() {
+                if (blk < 8) prefetch<4>(wb, LAY.l1_w[blk < 8 ? blk + 1 : 8], nt2, pre);
+                else prefetch<4>(wb, LAY.pc_w, 0, pre);
+            }, epi);
         }
         __syncthreads();
         NET_STAMP(4 + 3 * blk);
@@ -340,11 +416,10 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
         const float bv = W[LAY.pc_b + l15];
         auto epi = [&](int mt, const f32x4 &acc) {
             for_each_out(mt, acc, [&](int row, int col, float v) {
-                const float o = v + bv;
-                pc[row * 16 + col] = o > 0.f ? o : 0.f;
+                pc[row * 16 + col] = relu(v + bv);
             });
         };
-        gemm_tiles<2>(W + LAY.pc_w, 0, 4, mt0, afrag, epi);
+        gemm_tiles<2, 4>(wb, LAY.pc_w, 0, mt0, pre, afrag, []() {}, epi);
     }
     // ---- value head, part 1: 1x1 64 -> 1 (+ReLU) per row, into y2[0..199] -----------------------------
     float *vc = S.y2;                                    // [200]
