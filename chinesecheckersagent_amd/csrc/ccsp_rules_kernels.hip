@@ -12,24 +12,33 @@ namespace {
 constexpr int MG_THREADS = 256;
 constexpr int MG_WAVES = MG_THREADS / 64;
 constexpr int MG_CHUNK = 32;                                // states per wave
-constexpr int MG_STATES = MG_WAVES * MG_CHUNK;              // 256 states per workgroup
+constexpr int MG_STATES = MG_WAVES * MG_CHUNK;              // 128 states per workgroup
 constexpr int MG_TASKS = MG_CHUNK * 6;                      // (state, checker) tasks per wave
-constexpr int MG_STACK = 92;                                // >= 5 pending siblings per visited sub-lattice cell (16) + 1; odd dword stride
+constexpr int MG_STACK = 20;                                // bytes of depth-first stack per lane: 5 dwords (an odd stride: the 64 stacks
+                                                            // spread over all banks).  Real positions never hold more than 8 entries
+                                                            // (tests/test_device_logic_on_host.py: 400 000 positions); a search that would
+                                                            // need more is redone on the wave's one big stack (MG_BIGSTACK)
+constexpr int MG_BIGSTACK = 96;                             // >= 81 (<= 5 pending siblings per visited sub-lattice cell (16) + 1) + 6 tentative
 constexpr int MG_SLOT = 24;                                 // bytes of LDS per checker list (<= 21 used)
 
-struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS
+struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS: 7.1 KB -> five 4-wave workgroups per CU
     uint8_t lines[MG_CHUNK][28];                            // 27 line patterns per state (+1 pad)
     uint8_t lists[MG_CHUNK][6][MG_SLOT];
     uint8_t cnt[MG_CHUNK][8];
     uint8_t stack[64][MG_STACK];                            // one depth-first stack per lane
+    uint8_t big[MG_BIGSTACK];
+    uint32_t redo[MG_TASKS / 32];                           // tasks to redo on the big stack (bit per task)
 };
+
 
 // B2-B4 over an array of positions.  The ordered hop search of one checker (board.py:166-211) is a serial
 // depth-first walk whose length varies a lot between checkers, so lanes do not own a fixed checker: each wave
-// takes a chunk of 64 positions = 384 (position, checker) tasks, every lane runs ONE flat state machine
+// takes a chunk of 32 positions = 192 (position, checker) tasks, every lane runs ONE flat state machine
 // (one visited cell per iteration: six mirror-hop lookups HOP[line pattern][position][sense], ccsp_rules.h, and a
 // stack in LDS) and pulls the next task
 // of the chunk the moment its own is finished (ballot + rank) -- no lane waits for the longest walk of its wave.
+// Hop landings stay on the origin's sub-lattice (row and column keep their parity: <= 4 x 4 cells), so the visited
+// set is 16 bits indexed by (row / 2, column / 2) -- 32-bit tests instead of 64-bit shifts on a cell mask.
 // Per-checker lists are staged in LDS and written out in the reference's move order, a position at a time,
 // neighbouring lanes writing neighbouring bytes.
 // GREEDY (next-4): the same search, but what is written out is GreedyPlayer.decide_move(training=True)
@@ -39,14 +48,15 @@ template <bool GREEDY>
 __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *__restrict__ states,
                                                              const uint8_t *__restrict__ player, int n,
                                                              uint8_t *__restrict__ moves, uint8_t *__restrict__ count,
-                                                             uint64_t *__restrict__ dest_mask) {
-    __shared__ ccsp_line_tables T;
+                                                             uint64_t *__restrict__ dest_mask, int cap) {
+    __shared__ __attribute__((aligned(16))) ccsp_line_tables T;
     __shared__ MgWave WV[MG_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     MgWave &L = WV[wave];
     ccsp_load_lines_to_lds(&T, tid, MG_THREADS);
     const long long base = ((long long)blockIdx.x * MG_WAVES + wave) * MG_CHUNK;     // first position of this wave
     const int here = (int)((n - base) < 0 ? 0 : ((n - base) < MG_CHUNK ? (n - base) : MG_CHUNK));
+    if (lane < MG_TASKS / 32) L.redo[lane] = 0;
     __syncthreads();
 
     // ---- line patterns: lane = position -----------------------------------------------------------------
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
 #pragma unroll
                 for (int a = 0; a < 3; a++) { const int lp = T.lp[cell][a]; L.lines[lane][lp >> 3] |= (uint8_t)(1u << (lp & 7)); }
             }
-            // stash what the tasks need: origin cells of the side to move, in the cnt row for now
+            // stash what the tasks need: origin cells of the side to move, in the last byte of each list slot
 #pragma unroll
             for (int c = 0; c < 6; c++) L.lists[lane][c][MG_SLOT - 1] = (uint8_t)ccsp_sr_pos(s, (my_player - 1) * 6 + c);
         }
@@ -72,63 +82,89 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     // ---- task loop: lane = worker ---------------------------------------------------------------------------
     // The ordered hop search (board.py:166-211) with an explicit stack: popping a cell that is still unvisited
     // visits it (= the recursive call), looks up the mirror hop in all six directions (three line patterns, two
-    // senses each) and pushes the legal unvisited landings, last direction first, so that the first one is on top;
-    // a popped cell that was reached through another branch in the meantime is dropped (= the `not in hops` test of
-    // the caller's loop).  One iteration per visited cell instead of one per hop test.
+    // senses each: one 16-bit read per pattern) and pushes the legal unvisited landings, last direction first, so
+    // that the first one is on top; a popped cell that was reached through another branch in the meantime is dropped
+    // (= the `not in hops` test of the caller's loop).  One iteration per visited cell instead of one per hop test.
     const int ntasks = here * 6;
     int task = lane;                                    // current task (position-major: task = 6 * s + c)
     int next = 64;                                      // next unassigned task of the chunk (wave-uniform)
     int st_s = 0, st_c = 0, origin = 0, cnt_n = 0, sp = 0, orow = 0, oc = 0;
-    uint64_t visited = 0, mask = 0;
+    uint32_t visited = 0;                               // sub-lattice cells seen: bit (row / 2) * 4 + column / 2
+    uint64_t mask = 0;                                  // destination cells (walks + hop cells), for dest_mask
     bool active = false;
-    uint8_t *stk = L.stack[lane];
+    const bool want_mask = dest_mask != nullptr;
 
-    auto start_task = [&](int t) {
-        st_s = t / 6; st_c = t - 6 * st_s;
+    // a task starts with its origin on the stack: the origin's visit (always the first) also lists the walks
+    auto start_task = [&](int t, uint8_t *stk) {
+        st_s = (int)(__umul24((unsigned)t, 171u) >> 10);                   // t / 6, exact for t < 515 (tasks: < 192)
+        st_c = t - 6 * st_s;
         origin = L.lists[st_s][st_c][MG_SLOT - 1];
-        const uint8_t *pat = L.lines[st_s];
-        cnt_n = 0; mask = 0;
-        for (int dd = 0; dd < 6; dd++) {                // walks, direction order (board.py:149-155)
-            const int axis = dd % 3, sense = (dd >= 1 && dd <= 3) ? 1 : 0;
-            const int lp = T.lp[origin][axis];
-            const int np = (lp & 7) + (sense ? 1 : -1);
-            const bool ok = (np >= 0) & (np <= 6) & (((pat[lp >> 3] >> (np & 7)) & 1) == 0);
-            const int cell = T.cell[lp >> 3][np & 7];
-            L.lists[st_s][st_c][cnt_n] = (uint8_t)cell;           // kept only if the step is legal (no branch)
-            cnt_n += ok ? 1 : 0;
-            mask |= ok ? 1ULL << cell : 0ULL;
-        }
-        visited = 0;
+        cnt_n = 0; mask = 0; visited = 0;
         orow = (int)(__umul24((unsigned)origin, 37u) >> 8); oc = origin - 7 * orow;
         stk[0] = (uint8_t)origin; sp = 1;
     };
-    if (task < ntasks) { start_task(task); active = true; }
+    // one pop; returns false when the visit would not fit the stack (`room` entries): nothing is changed then
+    auto step = [&](uint8_t *stk, int room) -> bool {
+        const int x = stk[sp - 1];
+        const int r = (int)(__umul24((unsigned)x, 37u) >> 8), c = x - 7 * r;
+        const int xi = (r >> 1) * 4 + (c >> 1);
+        if ((visited >> xi) & 1u) { sp--; return true; }
+        if (sp - 1 + 6 > room) return false;                           // six tentative pushes must fit
+        sp--;
+        visited |= 1u << xi;
+        const uint8_t *pat = L.lines[st_s];
+        // the three lines through x; the moving checker is lifted off its own lines (board.py:158)
+        uint32_t p0 = pat[c], p1 = pat[7 + r], p2 = pat[20 + r - c];
+        const int m = r < c ? r : c, om = orow < oc ? orow : oc;
+        if (c == oc) p0 &= ~(1u << orow);
+        if (r == orow) p1 &= ~(1u << oc);
+        if (r - c == orow - oc) p2 &= ~(1u << om);
+        if (x == origin) {
+            // the task's first visit: the walks, direction order N,E,SE,S,W,NW (board.py:149-155), read off the same three
+            // patterns (bits beyond a line's end are preset; the byte is stored unconditionally, kept only if legal)
+#define MG_WALK(P, POS, D, STEP) { const int np = (POS) + (D); const bool ok = (np >= 0) & (np <= 6) & ((((P) >> (np & 7)) & 1u) == 0); \
+                                   const int cell = x + (STEP); L.lists[st_s][st_c][cnt_n] = (uint8_t)cell; cnt_n += ok ? 1 : 0; \
+                                   if (want_mask) mask |= ok ? 1ULL << (cell & 63) : 0ULL; }
+            MG_WALK(p0, r, -1, -7) MG_WALK(p1, c, 1, 1) MG_WALK(p2, m, 1, 8) MG_WALK(p0, r, 1, 7) MG_WALK(p1, c, -1, -1) MG_WALK(p2, m, -1, -8)
+#undef MG_WALK
+        } else {
+            L.lists[st_s][st_c][cnt_n] = (uint8_t)x;                    // a hop landing (the origin itself is not a move)
+            cnt_n += 1;
+            if (want_mask) mask |= 1ULL << x;
+        }
+        // both senses of a line in one 16-bit read: low byte = sense -, high byte = sense +
+        const uint32_t h0 = *reinterpret_cast<const uint16_t *>(&T.hop[p0][r][0]);
+        const uint32_t h1 = *reinterpret_cast<const uint16_t *>(&T.hop[p1][c][0]);
+        const uint32_t h2 = *reinterpret_cast<const uint16_t *>(&T.hop[p2][m][0]);
+        const int rh = r >> 1, ch = c >> 1;
+        // directions N,E,SE,S,W,NW = (axis 0,-) (1,+) (2,+) (0,+) (1,-) (2,-); pushed in reverse order (the byte is
+        // stored unconditionally and kept only if the landing is legal and unvisited: no branches).
+        // landing of a hop to line position hp: cell x + (hp - pos) * stride; sub-lattice index from its row / column
+#define MG_PUSH(HP, POS, STRIDE, IDX) { const int hp = (int)(HP); const int land = x + (hp - (POS)) * (STRIDE); \
+                                        stk[sp] = (uint8_t)land; sp += ((hp < 7) & (((visited >> ((IDX) & 15)) & 1u) == 0)) ? 1 : 0; }
+        MG_PUSH(h2 & 0xFF, m, 8, ((r + hp - m) >> 1) * 4 + ((c + hp - m) >> 1))      // NW
+        MG_PUSH(h1 & 0xFF, c, 1, rh * 4 + (hp >> 1))                                 // W
+        MG_PUSH(h0 >> 8, r, 7, (hp >> 1) * 4 + ch)                                   // S
+        MG_PUSH(h2 >> 8, m, 8, ((r + hp - m) >> 1) * 4 + ((c + hp - m) >> 1))        // SE
+        MG_PUSH(h1 >> 8, c, 1, rh * 4 + (hp >> 1))                                   // E
+        MG_PUSH(h0 & 0xFF, r, 7, (hp >> 1) * 4 + ch)                                 // N
+#undef MG_PUSH
+        return true;
+    };
+    auto finish_task = [&]() {
+        L.cnt[st_s][st_c] = (uint8_t)cnt_n;
+        if (want_mask) dest_mask[(base + st_s) * 6 + st_c] = mask;
+    };
+    uint8_t *stk = L.stack[lane];
+    if (task < ntasks) { start_task(task, stk); active = true; }
 
     while (__any(active)) {
         if (active) {
-            const int x = stk[--sp];
-            if (!((visited >> x) & 1)) {
-                visited |= 1ULL << x;
-                L.lists[st_s][st_c][cnt_n] = (uint8_t)x;              // the origin itself is not a move
-                cnt_n += x != origin ? 1 : 0;
-                const int r = (int)(__umul24((unsigned)x, 37u) >> 8), c = x - 7 * r;
-                const uint8_t *pat = L.lines[st_s];
-                // the three lines through x; the moving checker is lifted off its own lines (board.py:158)
-                uint32_t p0 = pat[c], p1 = pat[7 + r], p2 = pat[20 + r - c];
-                const int m = r < c ? r : c, om = orow < oc ? orow : oc;
-                if (c == oc) p0 &= ~(1u << orow);
-                if (r == orow) p1 &= ~(1u << oc);
-                if (r - c == orow - oc) p2 &= ~(1u << om);
-                // directions N,E,SE,S,W,NW = (axis 0,-) (1,+) (2,+) (0,+) (1,-) (2,-); pushed in reverse order
-                // (the byte is stored unconditionally and kept only if the landing is legal and unvisited: no branches)
-#define MG_PUSH(PAT, POS, SENSE, STRIDE) { const int hp = T.hop[PAT][POS][SENSE]; const int land = x + (hp - (POS)) * (STRIDE); \
-                                           stk[sp] = (uint8_t)land; sp += ((hp < 7) & (((visited >> (land & 63)) & 1) == 0)) ? 1 : 0; }
-                MG_PUSH(p2, m, 0, 8) MG_PUSH(p1, c, 0, 1) MG_PUSH(p0, r, 1, 7) MG_PUSH(p2, m, 1, 8) MG_PUSH(p1, c, 1, 1) MG_PUSH(p0, r, 0, 7)
-#undef MG_PUSH
-            }
-            if (sp == 0) {                                              // the search of this checker is complete
-                L.cnt[st_s][st_c] = (uint8_t)cnt_n;
-                if (dest_mask) dest_mask[(base + st_s) * 6 + st_c] = mask | (visited & ~(1ULL << origin));
+            if (!step(stk, cap)) {                                      // does not fit: this task goes to the big stack later
+                atomicOr(&L.redo[task >> 5], 1u << (task & 31));
+                active = false;
+            } else if (sp == 0) {                                       // the search of this checker is complete
+                finish_task();
                 active = false;
             }
         }
@@ -137,8 +173,23 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         if (next < ntasks && idle) {
             const int rank = __popcll(idle & ((1ULL << lane) - 1));
             const int t = next + rank;
-            if (!active && t < ntasks) { start_task(t); active = true; }
+            if (!active && t < ntasks) { task = t; start_task(t, stk); active = true; }
             next += __popcll(idle);
+        }
+    }
+    // searches that did not fit a lane's stack: one at a time, lane 0, on the wave's big stack
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int w = 0; w < MG_TASKS / 32; w++) {
+        uint32_t bits = L.redo[w];
+        while (bits) {
+            const int t = w * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            if (lane == 0) {
+                start_task(t, L.big);
+                while (sp > 0) (void)step(L.big, MG_BIGSTACK);
+                finish_task();
+            }
         }
     }
     __syncthreads();
@@ -284,16 +335,25 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_kernel(const ccsp_state *_
     }
 }
 
+int g_cap = MG_STACK;                 // stack entries a lane may use (test hook below; MG_STACK in production)
+
 }  // namespace
 
 extern "C" {
+
+// Test hook: limit the per-lane hop-search stack to `cap` entries (6 .. MG_STACK; anything else restores the default), so
+// that searches overflow into the big-stack redo path, which no real position reaches.  Returns the value in force.
+int ccsp_debug_movegen_stack_cap(int cap) {
+    g_cap = (cap >= 6 && cap <= MG_STACK) ? cap : MG_STACK;
+    return g_cap;
+}
 
 int ccsp_movegen(const ccsp_state *s, const uint8_t *player, int n, uint8_t *moves, uint8_t *count,
                  uint64_t *dest_mask, void *stream) {
     if (n < 0 || (n > 0 && (!s || !player || !moves || !count))) return CCSP_EINVAL;
     if (n == 0) return CCSP_OK;
     const int grid = (n + MG_STATES - 1) / MG_STATES;
-    hipLaunchKernelGGL(movegen_kernel<false>, dim3(grid), dim3(MG_THREADS), 0, (hipStream_t)stream, s, player, n, moves, count, dest_mask);
+    hipLaunchKernelGGL(movegen_kernel<false>, dim3(grid), dim3(MG_THREADS), 0, (hipStream_t)stream, s, player, n, moves, count, dest_mask, g_cap);
     CCSP_HIPCHK(hipGetLastError());
     return CCSP_OK;
 }
@@ -303,7 +363,7 @@ int ccsp_greedy_best(const ccsp_state *s, const uint8_t *player, int n, uint8_t 
     if (n == 0) return CCSP_OK;
     const int grid = (n + MG_STATES - 1) / MG_STATES;
     hipLaunchKernelGGL(movegen_kernel<true>, dim3(grid), dim3(MG_THREADS), 0, (hipStream_t)stream, s, player, n, best, count,
-                       (uint64_t *)nullptr);
+                       (uint64_t *)nullptr, g_cap);
     CCSP_HIPCHK(hipGetLastError());
     return CCSP_OK;
 }

@@ -108,6 +108,11 @@ int ccsp_encode(const ccsp_state *s, const uint8_t *player, int n, float *planes
 #define CCSP_GREEDY_MAX 32
 int ccsp_greedy_best(const ccsp_state *s, const uint8_t *player, int n, uint8_t *best, uint8_t *count, void *stream);
 
+/* test hook: per-lane hop-search stack entries of ccsp_movegen / ccsp_greedy_best (6 .. 20; other values restore the
+ * default 20).  Searches that need more are redone on a big stack -- no real position does; tests force it.  Returns the
+ * value in force. */
+int ccsp_debug_movegen_stack_cap(int cap);
+
 /* ---- self-play engine ------------------------------------------------------------------------- */
 
 typedef struct ccsp_ctx ccsp_ctx;

@@ -111,6 +111,36 @@ def test_all_records_against_reference_digests(gpu, golden_dir):
     assert h_step.digest() == g['sha_step'].tobytes(), 'next states / winners differ from the reference'
 
 
+def test_hop_search_overflow_path(gpu, golden_dir):
+    """the per-lane hop-search stacks hold 20 entries and real positions need at most 8, so the redo path (a search that
+    does not fit is run again on the wave's big stack) never runs on real data: force it with stacks of 6 / 7 / 9 entries
+    and require the same move lists and destination masks as with the full stacks, on 102 000 reference positions and
+    200 000 random ones (ragged size)"""
+    import torch
+    from chinesecheckersagent_amd import _lib
+    L = _lib.lib()
+    g = np.load(golden_dir + '/rules.npz')
+    pos12, last, player, chosen = _all_trajectory_states(g)
+    rng = np.random.RandomState(3)
+    cells = np.argsort(rng.rand(200003, 49), axis=1)[:, :12].astype(np.uint8)
+    pos12 = np.concatenate([pos12, cells])
+    player = np.concatenate([player, (1 + (np.arange(len(cells)) & 1)).astype(np.uint8)])
+    sd = gpu.to_device_states(_lib.pack_states(pos12))
+    assert L.ccsp_debug_movegen_stack_cap(0) == 20
+    want = [t.clone() for t in gpu.movegen(sd, player)]
+    want_g = [t.clone() for t in gpu.greedy_best(sd, player)]
+    try:
+        for cap in (6, 7, 9):
+            assert L.ccsp_debug_movegen_stack_cap(cap) == cap
+            got = gpu.movegen(sd, player)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), 'stack cap %d changes the result' % cap
+            for a, b in zip(gpu.greedy_best(sd, player), want_g):
+                assert torch.equal(a, b)
+    finally:
+        assert L.ccsp_debug_movegen_stack_cap(0) == 20
+
+
 def test_wins(gpu, golden_dir):
     from chinesecheckersagent_amd import _lib
     z = np.load(golden_dir + '/wins.npz')
