@@ -528,6 +528,14 @@ def extras(eng, G, S, torch, _lib, engine):
     c1 = e.counters()
     e.close()
     plies = c1['plies'] - c0['plies']
+    try:                                          # HBM bytes per state from the committed rocprofv3 counter passes (static)
+        prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))
+        for name, key in (('movegen_kernel', 'movegen_kernel<false>'), ('step_kernel', 'step_kernel'), ('encode_kernel', 'encode_kernel'),
+                          ('greedy_best_kernel', 'movegen_kernel<true>')):
+            v[name]['hbm_bytes_per_state_counters'] = prof[key]['hbm_bytes_per_state']
+            v[name]['counters_source'] = 'static: profiles/counters.json (2 x FETCH_SIZE + WRITE_SIZE, n = %d)' % prof[key]['n']
+    except Exception:
+        pass
     v['greedy_data_generator'] = {'games_per_s': (c1['games_won'] + c1['games_discarded'] - c0['games_won'] - c0['games_discarded']) / wall,
                                   'plies_per_s': plies / wall, 'samples_per_s': (c1['samples'] - c0['samples']) / wall,
                                   'achieved_GBps': plies * 2400 / wall / 1e9, 'frac_of_hbm_peak': plies * 2400 / wall / 1e9 / HBM_PEAK_GBPS,

@@ -42,5 +42,5 @@ if what in ('all', 'fused'):
     e.play_plies(_lib.EVAL_UNIFORM, 10)
     torch.cuda.synchronize()
     e.close()
-if what in ('all', 'stepped'):
+if what == 'stepped':            # hipGraph replays: NOT under --pmc (the counter passes never finished with it)
     print(sp.bench_net_plies(4096, 400, plies=1))

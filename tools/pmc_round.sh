@@ -12,7 +12,9 @@ sets=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INS
 i=0
 for set in "${sets[@]}"; do
   i=$((i+1)); d=/tmp/pmc_${tag}_$i; rm -rf $d
-  timeout -k 10 420 rocprofv3 --kernel-trace --output-format csv --pmc $set -d $d -- python3 tools/kernels_once.py $what > $d.log 2>&1 || { echo "pass $i failed"; tail -3 $d.log; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --output-format csv --pmc $set -d $d -- python3 tools/kernels_once.py $what > $d.log 2>&1
+  rc=$?
+  if [ $rc -ne 0 ]; then echo "pass $i failed (rc $rc)"; tail -3 $d.log; [ $rc -ge 124 ] && { echo "a pass was killed: no further passes"; break; }; fi
   f=$(find $d -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/${tag}_pmc_pass$i.csv
   echo "pass $i ($set): $(wc -l < gpurun_out/${tag}_pmc_pass$i.csv 2>/dev/null) rows"
