@@ -155,7 +155,7 @@ __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, in
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < NMT; i++)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb & 1][i][j], b[j], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i], 0, 0, 0);   // D^T: see tile_out
         }
     }
     next();
@@ -198,11 +198,11 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < NMT; i++)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb & 1][i][j], b[j], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i], 0, 0, 0);   // D^T: see tile_out
         }
         if ((kb >= kb0) & (kb < kb1)) {                                 // wave-uniform: ONE scalar branch per k-block
 #pragma unroll
-            for (int j = 0; j < 4; j++) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb & 1][NMT][j], b[j], accx, 0, 0, 0);
+            for (int j = 0; j < 4; j++) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], accx, 0, 0, 0);
         }
     }
     next();
@@ -220,7 +220,7 @@ __device__ __forceinline__ void reduce_split_tile(const float (*part)[4][256], f
     const int tid = threadIdx.x;
     if (tid < 512) {
         const int nt = tid >> 8, e = tid & 255, lane = e >> 2, reg = e & 3;
-        const int row = xmt * 16 + 4 * (lane >> 4) + reg, col = nt * 16 + (lane & 15);
+        const int row = xmt * 16 + (lane & 15), col = nt * 16 + 4 * (lane >> 4) + reg;      // transposed fragment (tile_out)
         const float v = ((part[nt][0][e] + part[nt][1][e]) + part[nt][2][e]) + part[nt][3][e] + bias;
         if (PADDED) {                                                       // 3x3 input: interior cell of the zero-halo copy
             const int sp = row / 25, pos = row % 25;
@@ -231,7 +231,13 @@ __device__ __forceinline__ void reduce_split_tile(const float (*part)[4][256], f
     }
 }
 
-// D fragment -> rows: lane holds column (lane & 15) of rows 16 mt + 4 (lane >> 4) + reg
+// The layer GEMMs pass the WEIGHTS as the MFMA's first operand and the activations as its second: the instruction then
+// produces the transposed tile, and a lane holds, for ONE activation row (16 mt + (lane & 15)), FOUR CONSECUTIVE output
+// channels (16 nt + 4 (lane >> 4) + 0..3) -- one 16-byte LDS store per tile (and one 16-byte read for the residual) where
+// the untransposed fragment (a column of four rows) needs four 4-byte ones.  The packed weight order serves both ways
+// round: lane (l15, q) holds W[k = 4 q + j][n = l15] for either operand slot.
+//
+// D fragment of the policy dense layer (untransposed): lane holds column (lane & 15) of rows 16 mt + 4 (lane >> 4) + reg
 template <typename F>
 __device__ __forceinline__ void for_each_out(int mt, const f32x4 &acc, F f) {
     const int lane = threadIdx.x & 63;
@@ -277,8 +283,10 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
 #endif
 
     const int nt2 = wave & 1, qr = wave >> 1, mt3 = 3 * qr;      // this wave's share of the 32-column layers (see below)
-    const int rcol = (tid >> 8) * 16 + (((tid & 255) >> 2) & 15);   // the column this thread finishes in reduce_split_tile
+    const int rcol = (tid >> 8) * 16 + 4 * ((tid & 255) >> 6) + (tid & 3);   // the column this thread finishes in reduce_split_tile
     f32x4 pre[NPREMAX];                                          // the next layer's first weight k-blocks, in flight across barriers
+    auto bias4 = [&](int off) -> f32x4 { return *reinterpret_cast<const f32x4 *>(W + off + 4 * q); };   // this lane's four output channels
+    auto relu4 = [](const f32x4 &v) -> f32x4 { return f32x4{relu(v[0]), relu(v[1]), relu(v[2]), relu(v[3])}; };
 
     // ---- stem: 3x3 valid, K = 9 taps x 8 -> 5 k-blocks of 2 taps (10th tap = zero weights) -----------
     // A row's nine taps are plain offsets from its top-left input cell (valid convolution); rows past the 200th and the
@@ -301,11 +309,9 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
         auto afrag = [&](int, int kb, int i) -> f32x4 {
             return *reinterpret_cast<const f32x4 *>(&in[sbase[i] + tapoff[kb]]);
         };
-        const float bv = W[LAY.stem_b + nt * 16 + l15];        // this lane's output column
+        const f32x4 bv = bias4(LAY.stem_b + nt * 16);
         auto epi = [&](int mt, const f32x4 &acc) {
-            for_each_out(mt, acc, [&](int row, int col, float v) {
-                S.x[row * LDX + nt * 16 + col] = relu(v + bv);
-            });
+            *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = relu4(acc + bv);
         };
         prefetch<5>(wb, LAY.stem_w, nt, pre);
         gemm_tiles<7, 5>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
@@ -319,8 +325,8 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     // 32-column layers: a wave owns row tiles 3 qr .. 3 qr + 2 of column tile nt, and a quarter of tile 12's k-range.
     // Per slot (0-2: the full tiles; 3: tile 12), once for all nine blocks:
     //   a3[i]     element offset in y1 of the row's TOP-LEFT tap (zero-halo copy): tap (dr, dc) is + (dr*7 + dc) * LDY
-    //   prow[i][] element offsets in y1 of the four interior cells this lane's D fragment holds (1x1 epilogue -> 3x3 input)
-    int a3[4], prow[3][4];
+    //   prow[i]   element offset in y1 of the interior cell of this lane's row of tile i (1x1 epilogue -> 3x3 input)
+    int a3[4], prow[3];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int row = (i < 3 ? mt3 + i : 12) * 16 + l15;
@@ -329,13 +335,11 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
         a3[i] = (s * 49 + (pos / 5) * 7 + (pos % 5)) * LDY + 4 * q;
     }
 #pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int row = (mt3 + i) * 16 + 4 * q + reg;      // < 192: always a real cell
-            const int s = row / 25, pos = row % 25;
-            prow[i][reg] = (s * 49 + (pos / 5 + 1) * 7 + (pos % 5 + 1)) * LDY;
-        }
+    for (int i = 0; i < 3; i++) {
+        const int row = (mt3 + i) * 16 + l15;                  // < 192: always a real cell
+        const int s = row / 25, pos = row % 25;
+        prow[i] = (s * 49 + (pos / 5 + 1) * 7 + (pos % 5 + 1)) * LDY + 4 * q;
+    }
 
     // ---- nine bottleneck residual blocks (model.py:120-145) ------------------------------------------
     float rbias;
@@ -344,13 +348,11 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
             auto afrag = [&](int mt, int kb, int) -> f32x4 {
                 return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
             };
-            const float bv = W[LAY.l1_b[blk] + nt2 * 16 + l15];
+            const f32x4 bv = bias4(LAY.l1_b[blk] + nt2 * 16);
             rbias = W[LAY.l1_b[blk] + rcol];
             auto epi = [&](int mt, const f32x4 &acc) {
                 const int i = mt - mt3;
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++)
-                    S.y1[(i == 0 ? prow[0][reg] : (i == 1 ? prow[1][reg] : prow[2][reg])) + nt2 * 16 + l15] = relu(acc[reg] + bv);
+                *reinterpret_cast<f32x4 *>(&S.y1[(i == 0 ? prow[0] : (i == 1 ? prow[1] : prow[2])) + nt2 * 16]) = relu4(acc + bv);
             };
             gemm_tiles_split<3, 4>(wb, LAY.l1_w[blk], nt2, mt3, 12, qr, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); }, epi,
                                    S.part[nt2][qr]);
@@ -364,12 +366,10 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
                 const int tap = kb >> 1;                                        // compile-time after unrolling
                 return *reinterpret_cast<const f32x4 *>(&S.y1[a3[i] + ((tap / 3) * 7 + tap % 3) * LDY + (kb & 1) * 16]);
             };
-            const float bv = W[LAY.l2_b[blk] + nt2 * 16 + l15];
+            const f32x4 bv = bias4(LAY.l2_b[blk] + nt2 * 16);
             rbias = W[LAY.l2_b[blk] + rcol];
             auto epi = [&](int mt, const f32x4 &acc) {
-                for_each_out(mt, acc, [&](int row, int col, float v) {
-                    S.y2[row * LDY + nt2 * 16 + col] = relu(v + bv);
-                });
+                *reinterpret_cast<f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + nt2 * 16 + 4 * q]) = relu4(acc + bv);
             };
             gemm_tiles_split<3, 18>(wb, LAY.l2_w[blk], nt2, mt3, 12, qr, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
                                     S.part[nt2][qr]);
@@ -390,12 +390,10 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
             auto afrag = [&](int mt, int kb, int) -> f32x4 {
                 return *reinterpret_cast<const f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + kb * 16 + 4 * q]);
             };
-            const float bv = W[LAY.l3_b[blk] + nt * 16 + l15];
+            const f32x4 bv = bias4(LAY.l3_b[blk] + nt * 16);
             auto epi = [&](int mt, const f32x4 &acc) {
-                for_each_out(mt, acc, [&](int row, int col, float v) {
-                    float *px = &S.x[row * LDX + nt * 16 + col];
-                    *px = relu(v + bv + *px);                                   // add([x, block_input]) then ReLU
-                });
+                f32x4 *px = reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]);
+                *px = relu4(acc + bv + *px);                                    // add([x, block_input]) then ReLU
             };
             gemm_tiles<7, 2>(wb, LAY.l3_w[blk], nt, mt0, pre, afrag, [&]() {
                 if (blk < 8) prefetch<4>(wb, LAY.l1_w[blk < 8 ? blk + 1 : 8], nt2, pre);
@@ -413,11 +411,9 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
         auto afrag = [&](int mt, int kb, int) -> f32x4 {
             return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
         };
-        const float bv = W[LAY.pc_b + l15];
+        const f32x4 bv = bias4(LAY.pc_b);
         auto epi = [&](int mt, const f32x4 &acc) {
-            for_each_out(mt, acc, [&](int row, int col, float v) {
-                pc[row * 16 + col] = relu(v + bv);
-            });
+            *reinterpret_cast<f32x4 *>(&pc[(mt * 16 + l15) * 16 + 4 * q]) = relu4(acc + bv);
         };
         gemm_tiles<2, 4>(wb, LAY.pc_w, 0, mt0, pre, afrag, []() {}, epi);
     }
