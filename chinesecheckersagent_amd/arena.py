@@ -14,7 +14,7 @@ from .selfplay import _batched, _default_seed
 
 class BatchArena(object):
     def __init__(self, model1, model2, n_games, sims=MCTS_SIMULATIONS, seed=None, first_game=0, tree_tau=DET_TREE_TAU,
-                 enforce_move_limit=False, alternate=False, device=0, greedy=0):
+                 enforce_move_limit=False, alternate=False, device=0, greedy=0, use_graph=True):
         import torch
         self.torch = torch
         self.m1, self.m2 = _batched(model1), _batched(model2 if model2 is not None else model1)
@@ -29,23 +29,68 @@ class BatchArena(object):
         self.swap = torch.from_numpy(swap).to(dev)
         self.swap_host = swap
         self.n_games, self.sims = n_games, sims
+        self._root_is_p2 = torch.zeros(n_games, dtype=torch.bool, device=dev)
+        self.use_graph, self._graph = bool(use_graph), None
 
     def _evaluate(self, root_is_p2):
         p1, v1 = self.m1.evaluate_batch(self.planes)
+        if self.m2 is self.m1:                            # one model on both sides: one forward, nothing to choose
+            return p1, v1
         p2, v2 = self.m2.evaluate_batch(self.planes)
         use2 = root_is_p2 ^ self.swap                     # AiPlayer(player_num=2, model=model2) (game.py:24-30)
         return self.torch.where(use2[:, None], p2, p1).contiguous(), self.torch.where(use2, v2, v1).contiguous()
 
+    def _capture(self, root_is_p2):
+        """the simulation steps of a move (select kernel -> forward(s) -> expand/backup kernel) captured once into a
+        hipGraph, several steps per graph, as selfplay.BatchSelfPlay does; falls back to plain launches if capture fails"""
+        torch, e = self.torch, self.eng
+        n = self.sims - 1
+        self._unroll = max(k for k in (24, 20, 16, 12, 10, 8, 6, 5, 4, 3, 2, 1) if n % k == 0) if n > 0 else 0
+        if not (self.use_graph and self._unroll and hasattr(self.m1, 'model') and hasattr(self.m2, 'model')):
+            self.use_graph = False
+            return
+        selected = False
+        try:
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):                   # warm-up on a side stream (allocator)
+                for _ in range(2):
+                    self._evaluate(root_is_p2)
+            torch.cuda.current_stream().wait_stream(st)
+            g = torch.cuda.CUDAGraph()
+            keep = []
+            with torch.cuda.graph(g):
+                for _ in range(self._unroll):
+                    e.select(self.planes)
+                    selected = True
+                    gp, gv = self._evaluate(root_is_p2)
+                    e.expand_backup(gp, gv)
+                    selected = False
+                    keep.append((gp, gv))
+            self._graph, self._graph_out = g, keep
+        except Exception:
+            self.use_graph, self._graph = False, None
+            if selected:                                  # close the half-captured step on the host side
+                p, v = self._evaluate(root_is_p2)
+                e.expand_backup(p, v)
+
     def play_move(self):
         e = self.eng
         e.ply_begin(self.planes)
-        root_is_p2 = self.planes[:, 0, 0, 6] == 1
+        self._root_is_p2.copy_(self.planes[:, 0, 0, 6] == 1)
+        root_is_p2 = self._root_is_p2
         p, v = self._evaluate(root_is_p2)
         e.root_expand(p, v)                               # = the search's first simulation (MCTS.py:123-125 on a leaf root)
-        for _ in range(self.sims - 1):
-            e.select(self.planes)
-            p, v = self._evaluate(root_is_p2)
-            e.expand_backup(p, v)
+        if self.use_graph and self._graph is None:
+            self._capture(root_is_p2)
+        if self._graph is not None:
+            for _ in range((self.sims - 1) // self._unroll):
+                self._graph.replay()
+        else:
+            for _ in range(self.sims - 1):
+                e.select(self.planes)
+                p, v = self._evaluate(root_is_p2)
+                e.expand_backup(p, v)
         e.ply_end()
 
     def run(self, max_moves=4096):

@@ -199,6 +199,15 @@ class Trainer(object):
             tot, cnt = 0.0, 0
             for i in range(0, split, batch_size):
                 idx = perm[i:i + batch_size]
+                if self.ddp is not None:
+                    # every rank draws the SAME permutation (same seed) and takes its own equal share of each global batch:
+                    # the gradient DistributedDataParallel averages is then the mean over the global batch, not N copies
+                    # of the same work; what does not divide by the world size is dropped from that batch
+                    import torch.distributed as dist
+                    world, rank = dist.get_world_size(), dist.get_rank()
+                    idx = idx[:len(idx) // world * world][rank::world]
+                    if len(idx) == 0:
+                        continue
                 l = self.step(xt[idx], pt[idx], zt[idx])[0]
                 tot += l * len(idx); cnt += len(idx)
             val = None
@@ -210,10 +219,12 @@ class Trainer(object):
         return hist
 
 
-def train(model_path, board_x, pi_y, v_y, data_retention, version, save_dir=SAVE_WEIGHTS_DIR, device=None, seed=0):
+def train(model_path, board_x, pi_y, v_y, data_retention, version, save_dir=SAVE_WEIGHTS_DIR, device=None, seed=0, ddp=False):
     """train.train (train.py:109-146): load weights, keep a random `data_retention` fraction of the samples
-    (train.py:134-137), fit, save 'saved-weights/version{version:0>4}-weights.h5'.  Returns the path."""
-    t = Trainer(device=device)
+    (train.py:134-137), fit, save 'saved-weights/version{version:0>4}-weights.h5'.  Returns the path.
+    ddp=True (one process per GPU, torch.distributed initialised by the caller): every rank calls this with the SAME
+    arrays and seed; fit() gives each rank its share of every batch, the replicas stay identical, rank 0's file is the result."""
+    t = Trainer(device=device, ddp=ddp)
     if model_path is not None:
         t.load_weights(model_path)
     n = len(v_y)

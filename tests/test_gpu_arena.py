@@ -63,3 +63,27 @@ def test_arena_api_two_models(golden_dir):
     assert w1 + w2 + d == 4
     r = arena.agent_match(TableModel(2), TableModel(2), 2, sims=8, seed=doc['seed'], first_game=7000)
     assert r is None or isinstance(r, TableModel)
+
+
+def test_arena_graph_replay_and_shared_model(golden_dir):
+    """the net arena's simulation steps replayed from a captured hipGraph, and one forward per step when both seats share
+    a model: the same games, move for move, as plain launches with two separately loaded copies of the model"""
+    import torch
+    from chinesecheckersagent_amd import arena
+    from chinesecheckersagent_amd.model import ResidualCNN
+    m = ResidualCNN(); m.load_weights(golden_dir + '/good_model.h5')
+    m2 = ResidualCNN(); m2.load_weights(golden_dir + '/good_model.h5')
+    out = []
+    for models, graph in (((m, None), True), ((m, m2), False)):
+        b = arena.BatchArena(models[0], models[1], 6, sims=13, seed=11, first_game=300, enforce_move_limit=True, alternate=True,
+                             use_graph=graph)
+        for _ in range(12):
+            b.play_move()
+        torch.cuda.synchronize()
+        assert (b._graph is not None) == graph and (b.m2 is b.m1) == graph
+        st, meta, pi = b.eng.log()
+        order = np.lexsort((meta['ply'], meta['game']))
+        out.append((st[order].tobytes(), pi[order].tobytes(), b.eng.counters()))
+        b.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert out[0][2]['errors'] == 0 and out[0][2]['samples'] == 6 * 12

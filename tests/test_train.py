@@ -119,7 +119,18 @@ def _ddp_rank(rank, world, port, q):
     z = torch.ones(16)
     for _ in range(2):
         t.step(x, pi, z)
-    q.put((rank, float(t.net.policy_head.weight.sum()), float(t.net.convs['5'].weight.abs().sum())))
+    # fit(): the same arrays on every rank; each rank must take its own half of every global batch of 8
+    gc = torch.Generator().manual_seed(7)
+    xs = torch.randint(0, 7, (42, 7, 7, 7), generator=gc).float().numpy()
+    ps = torch.softmax(torch.randn(42, 294, generator=gc), dim=1).numpy()
+    zs = np.ones(42, dtype=np.int64)
+    seen = []
+    step0 = t.step
+    t.step = lambda a, b, c: (seen.append(a.clone()), step0(a, b, c))[1]
+    t.fit(xs, ps, zs, batch_size=8, epochs=1, validation_split=0.0, seed=5)
+    rows = torch.cat(seen)
+    q.put((rank, float(t.net.policy_head.weight.sum()), float(t.net.convs['5'].weight.abs().sum()), [len(a) for a in seen],
+           float(rows.sum())))
     dist.destroy_process_group()
 
 
@@ -132,7 +143,9 @@ def test_ddp_gloo_world2_keeps_replicas_identical():
     [p.start() for p in ps]
     res = sorted(q.get(timeout=180) for _ in ps)
     [p.join(60) for p in ps]
-    assert res[0][1:] == res[1][1:]                        # gradient all-reduce: both replicas took the same step
+    assert res[0][1:3] == res[1][1:3]                      # gradient all-reduce: both replicas took the same steps
+    # 42 samples in global batches of 8: 5 x 4 per rank, then 2 -> 1 per rank; the two ranks saw DIFFERENT rows
+    assert res[0][3] == res[1][3] == [4, 4, 4, 4, 4, 1] and res[0][4] != res[1][4]
 
 
 def test_iteration_pooling_and_paths(tmp_path):
