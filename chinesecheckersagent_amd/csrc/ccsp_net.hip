@@ -34,8 +34,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NB = 8;                    // positions per workgroup
 constexpr int ROWS = NB * 25;            // 200
 constexpr int MT = 13;                   // 16-row tiles (208 rows, 8 of them padding)
-constexpr int MTP = 14;                  // tiles allocated: waves that split 13 tiles unevenly compute one phantom tile
-                                         // (rows 208..223) rather than branch around MFMAs
+constexpr int MTP = 13;                  // tiles allocated.  Waves that share 13 tiles seven-and-seven both compute tile 6 (same
+                                         // values; the second copy of a read-modify-write epilogue is skipped) rather than a
+                                         // 14th, phantom tile: its rows would cost 6.6 KB of LDS, and the 8.8 KB this leaves free
+                                         // per CU let a one-wave workgroup of the tree kernels (7.6 KB) run BESIDE the evaluator
+                                         // -- the other half-batch's select / expand kernels no longer wait for it
 #ifndef CCSP_NET_LDX
 #define CCSP_NET_LDX 68
 #define CCSP_NET_LDY 36
@@ -82,14 +85,14 @@ constexpr int PADROWS = NB * 49;         // 3x3 input with a zero halo: position
 constexpr int INROWS = 448;              // staged input planes: 8 x 49 cells + what phantom rows / the zero-weight 10th tap reach
 
 struct Smem {
-    float x[MTP * 16 * LDX];             // 64-channel trunk activations (60.9 KB)
+    float x[MTP * 16 * LDX];             // 64-channel trunk activations (56.6 KB)
     float y1[PADROWS * LDY];             // 32-channel 1x1 output = 3x3 input, zero halo (56.4 KB); the stem's input planes
                                          // and the policy conv output alias it
-    float y2[MTP * 16 * LDY];            // 32-channel 3x3 output (32.3 KB); logits / value scratch alias it
+    float y2[MTP * 16 * LDY];            // 32-channel 3x3 output (30.0 KB); logits / value scratch alias it
     float part[2][4][256];               // partial sums of the k-split row tile 12 of the 32-column layers (8 KB)
 };
 static_assert(INROWS * LDI <= PADROWS * LDY, "the staged input planes alias y1");
-static_assert(sizeof(Smem) <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
+static_assert(sizeof(Smem) + 7800 <= 160 * 1024, "one evaluator workgroup per CU plus room for a tree-kernel workgroup");
 
 // the packed weights as a buffer resource: loads take a scalar byte offset (+ the lane's 16 bytes), no vector address math
 struct WBuf {
@@ -113,7 +116,7 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
 // afrag(mt, kb, i) -> the lane's four A values of k-block kb for row tile mt (i = mt - mt0, a compile-time
 // slot for per-tile precomputed data);  epi(mt, acc) consumes a tile (bias, residual, ReLU: the bias is added AFTER the
 // sum as Keras does -- starting the accumulator from it costs accuracy: 2.6e-5 instead of 1.5e-5 worst logit).  wbase = float offset of the layer's packed weights.
-// No tile is ever skipped: a wave whose share ends past tile 12 computes phantom rows (allocated, never read).
+// No tile is ever skipped: where two waves share an odd number of tiles, both compute the middle one.
 // Register discipline of both loops (every index is static after unrolling): the A fragments of k-block kb live in
 // buffer kb & 1 and those of kb + 1 are read into the OTHER buffer, the weight ring slot refilled during k-block kb is the
 // one k-block kb - 1 used -- a load never targets a register an MFMA issued a moment ago still reads (the compiler would
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     // A row's nine taps are plain offsets from its top-left input cell (valid convolution); rows past the 200th and the
     // zero-weight 10th tap read staged zeros.  No masks in the loop.
     {
-        const int nt = wave & 3, mt0 = (wave >> 2) * 7;        // 4 column tiles x 2 row halves (tile 13 phantom)
+        const int nt = wave & 3, mt0 = (wave >> 2) * 6;        // 4 column tiles x 2 row halves: tiles 0-6 and 6-12 (tile 6 twice: a plain store)
         int sbase[7];
 #pragma unroll
         for (int i = 0; i < 7; i++) {
@@ -386,12 +389,13 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
         __syncthreads();
         NET_STAMP(3 + 3 * blk);
         {   // 1x1 32 -> 64 + residual: 4 column tiles x 2 row halves; the accumulators START from bias + block input
-            const int nt = wave & 3, mt0 = (wave >> 2) * 7;
+            const int nt = wave & 3, half = wave >> 2, mt0 = half * 6;       // tiles 0-6 and 6-12: tile 6 is computed by both halves ...
             auto afrag = [&](int mt, int kb, int) -> f32x4 {
                 return *reinterpret_cast<const f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + kb * 16 + 4 * q]);
             };
             const f32x4 bv = bias4(LAY.l3_b[blk] + nt * 16);
             auto epi = [&](int mt, const f32x4 &acc) {
+                if (half && mt == 6) return;                                    // ... and updated (read-modify-write) by the first only
                 f32x4 *px = reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]);
                 *px = relu4(acc + bv + *px);                                    // add([x, block_input]) then ReLU
             };
@@ -405,9 +409,9 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     }
 
     // ---- policy head: 1x1 64 -> 16 (+ReLU) into pc[row][16] (contiguous = [position][400]), aliasing y1 ----
-    float *pc = S.y1;                                    // [224][16] floats; only rows < 200 are read
+    float *pc = S.y1;                                    // [208][16] floats; only rows < 200 are read
     {
-        const int mt0 = wave < 6 ? 2 * wave : 12;            // two tiles per wave; waves 6 and 7 both take tiles 12, 13
+        const int mt0 = wave < 6 ? 2 * wave : 11;            // two tiles per wave; waves 6 and 7 both take tiles 11, 12 (plain stores)
         auto afrag = [&](int mt, int kb, int) -> f32x4 {
             return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
         };
