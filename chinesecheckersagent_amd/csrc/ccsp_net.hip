@@ -81,18 +81,22 @@ constexpr Layout LAY = make_layout();
 constexpr int PLAIN_TOTAL = 4032 + 64 + 9 * (2048 + 32 + 9216 + 32 + 2048 + 64) + 1024 + 16 + 117600 + 294 + 64 + 1 + 800 + 32 + 32 + 1;
 static_assert(PLAIN_TOTAL == 244920, "249852 parameters minus the 4 x 1233 BatchNorm values folded away");
 
-constexpr int PADROWS = NB * 49;         // 3x3 input with a zero halo: position s, cell (r, c) of the 5x5 map at row s*49 + (r+1)*7 + (c+1)
+// 3x3 input with a SHARED zero halo: position s, cell (r, c) of the 5x5 map sits at row PAD0 + 36 s + 6 r + c -- every map row
+// is followed by one zero cell (the right neighbour of column 4 AND the left neighbour of the next row's column 0), every map by
+// one zero row of six (the bottom halo of this map AND the top halo of the next).  Neighbour (dr, dc) = + 6 dr + dc.
+constexpr int PAD0 = 7, PADPOS = 36;
+constexpr int PADROWS = PAD0 + NB * PADPOS + 1;
 constexpr int INROWS = 448;              // staged input planes: 8 x 49 cells + what phantom rows / the zero-weight 10th tap reach
 
 struct Smem {
     float x[MTP * 16 * LDX];             // 64-channel trunk activations (56.6 KB)
-    float y1[PADROWS * LDY];             // 32-channel 1x1 output = 3x3 input, zero halo (56.4 KB); the stem's input planes
+    float y1[PADROWS * LDY];             // 32-channel 1x1 output = 3x3 input, zero halo (42.6 KB); the stem's input planes
                                          // and the policy conv output alias it
     float y2[MTP * 16 * LDY];            // 32-channel 3x3 output (30.0 KB); logits / value scratch alias it
     float part[2][4][256];               // partial sums of the k-split row tile 12 of the 32-column layers (8 KB)
 };
 static_assert(INROWS * LDI <= PADROWS * LDY, "the staged input planes alias y1");
-static_assert(sizeof(Smem) + 7800 <= 160 * 1024, "one evaluator workgroup per CU plus room for a tree-kernel workgroup");
+static_assert(sizeof(Smem) + 2 * 7800 <= 160 * 1024, "one evaluator workgroup per CU plus room for two tree-kernel workgroups");
 
 // the packed weights as a buffer resource: loads take a scalar byte offset (+ the lane's 16 bytes), no vector address math
 struct WBuf {
@@ -227,7 +231,7 @@ __device__ __forceinline__ void reduce_split_tile(const float (*part)[4][256], f
         const float v = ((part[nt][0][e] + part[nt][1][e]) + part[nt][2][e]) + part[nt][3][e] + bias;
         if (PADDED) {                                                       // 3x3 input: interior cell of the zero-halo copy
             const int sp = row / 25, pos = row % 25;
-            if (row < ROWS) y[(sp * 49 + (pos / 5 + 1) * 7 + (pos % 5 + 1)) * LDY + col] = relu(v);
+            if (row < ROWS) y[(PAD0 + sp * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + col] = relu(v);
         } else {
             y[row * LDY + col] = relu(v);
         }
@@ -321,13 +325,14 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     }
     __syncthreads();
     // the staged planes are dead: y1 becomes the zero-halo 3x3 input (only interior cells are ever written again)
+    static_assert((PADROWS * LDY) % 4 == 0, "y1 is cleared 16 bytes at a time");
     for (int i = tid * 4; i < PADROWS * LDY; i += NTH * 4) *reinterpret_cast<f32x4 *>(&S.y1[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     NET_STAMP(1);
 
     // 32-column layers: a wave owns row tiles 3 qr .. 3 qr + 2 of column tile nt, and a quarter of tile 12's k-range.
     // Per slot (0-2: the full tiles; 3: tile 12), once for all nine blocks:
-    //   a3[i]     element offset in y1 of the row's TOP-LEFT tap (zero-halo copy): tap (dr, dc) is + (dr*7 + dc) * LDY
+    //   a3[i]     element offset in y1 of the row's TOP-LEFT tap (zero-halo copy): tap (dr, dc) is + (dr*6 + dc) * LDY
     //   prow[i]   element offset in y1 of the interior cell of this lane's row of tile i (1x1 epilogue -> 3x3 input)
     int a3[4], prow[3];
 #pragma unroll
@@ -335,13 +340,13 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
         int row = (i < 3 ? mt3 + i : 12) * 16 + l15;
         if (row >= ROWS) row -= 25;                            // phantom rows of tile 12: any valid cell (results never read)
         const int s = row / 25, pos = row % 25;
-        a3[i] = (s * 49 + (pos / 5) * 7 + (pos % 5)) * LDY + 4 * q;
+        a3[i] = (s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;              // = cell (r - 1, c - 1): PAD0 - 7 = 0
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const int row = (mt3 + i) * 16 + l15;                  // < 192: always a real cell
         const int s = row / 25, pos = row % 25;
-        prow[i] = (s * 49 + (pos / 5 + 1) * 7 + (pos % 5 + 1)) * LDY + 4 * q;
+        prow[i] = (PAD0 + s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;
     }
 
     // ---- nine bottleneck residual blocks (model.py:120-145) ------------------------------------------
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
         {   // 3x3 same 32 -> 32: k-block kb = tap (kb >> 1), channels 16 (kb & 1) ..; the halo supplies the zeros
             auto afrag = [&](int, int kb, int i) -> f32x4 {
                 const int tap = kb >> 1;                                        // compile-time after unrolling
-                return *reinterpret_cast<const f32x4 *>(&S.y1[a3[i] + ((tap / 3) * 7 + tap % 3) * LDY + (kb & 1) * 16]);
+                return *reinterpret_cast<const f32x4 *>(&S.y1[a3[i] + ((tap / 3) * 6 + tap % 3) * LDY + (kb & 1) * 16]);
             };
             const f32x4 bv = bias4(LAY.l2_b[blk] + nt2 * 16);
             rbias = W[LAY.l2_b[blk] + rcol];
