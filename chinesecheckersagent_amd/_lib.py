@@ -61,6 +61,7 @@ _SIGS = {
     'ccsp_net_packed_size': (C.c_int, []),
     'ccsp_net_pack': (C.c_int, [_VP, _VP]),
     'ccsp_net_forward': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
+    'ccsp_debug_net_shape': (C.c_int, [C.c_int]),
     'ccsp_create': (_VP, [C.POINTER(Config), C.POINTER(C.c_int)]),
     'ccsp_destroy': (C.c_int, [_VP]),
     'ccsp_reset': (C.c_int, [_VP, _VP]),

@@ -31,14 +31,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NB = 8;                    // positions per workgroup
-constexpr int ROWS = NB * 25;            // 200
-constexpr int MT = 13;                   // 16-row tiles (208 rows, 8 of them padding)
-constexpr int MTP = 13;                  // tiles allocated.  Waves that share 13 tiles seven-and-seven both compute tile 6 (same
-                                         // values; the second copy of a read-modify-write epilogue is skipped) rather than a
-                                         // 14th, phantom tile: its rows would cost 6.6 KB of LDS, and the 8.8 KB this leaves free
-                                         // per CU let a one-wave workgroup of the tree kernels (7.6 KB) run BESIDE the evaluator
-                                         // -- the other half-batch's select / expand kernels no longer wait for it
 #ifndef CCSP_NET_LDX
 #define CCSP_NET_LDX 68
 #define CCSP_NET_LDY 36
@@ -47,6 +39,9 @@ constexpr int LDX = CCSP_NET_LDX;        // row stride of the 64-channel buffer 
 constexpr int LDY = CCSP_NET_LDY;        // row stride of the 32-channel buffers
 constexpr int LDI = 12;                  // input planes: 7 channels + zeros; 12 spreads eight consecutive cells over all banks
 constexpr int NPOL = 294, NPOL_PAD = 304;
+#ifndef CCSP_NET_SHAPE
+#define CCSP_NET_SHAPE 8                 // default workgroup shape of ccsp_net_forward (see Cfg)
+#endif
 
 // ---- packed weight blob layout (floats) ----------------------------------------------------------------
 struct Layout {
@@ -85,18 +80,37 @@ static_assert(PLAIN_TOTAL == 244920, "249852 parameters minus the 4 x 1233 Batch
 // is followed by one zero cell (the right neighbour of column 4 AND the left neighbour of the next row's column 0), every map by
 // one zero row of six (the bottom halo of this map AND the top halo of the next).  Neighbour (dr, dc) = + 6 dr + dc.
 constexpr int PAD0 = 7, PADPOS = 36;
-constexpr int PADROWS = PAD0 + NB * PADPOS + 1;
-constexpr int INROWS = 448;              // staged input planes: 8 x 49 cells + what phantom rows / the zero-weight 10th tap reach
-
-struct Smem {
-    float x[MTP * 16 * LDX];             // 64-channel trunk activations (56.6 KB)
-    float y1[PADROWS * LDY];             // 32-channel 1x1 output = 3x3 input, zero halo (42.6 KB); the stem's input planes
-                                         // and the policy conv output alias it
-    float y2[MTP * 16 * LDY];            // 32-channel 3x3 output (30.0 KB); logits / value scratch alias it
-    float part[2][4][256];               // partial sums of the k-split row tile 12 of the 32-column layers (8 KB)
+// A workgroup of NW waves carries NB positions (rows = position * 25 + cell, MT tiles of 16 rows).  Two shapes are built:
+//   <8, 8>: 200 rows = 13 tiles (4 % padding), one 137-KB workgroup per CU, two waves per SIMD from the SAME workgroup --
+//           at every barrier both are out of matrix work at once;
+//   <4, 4>: 100 rows = 7 tiles (12 % padding), 72 KB: TWO workgroups per CU, a SIMD's two waves belong to different
+//           workgroups whose barriers fall at different times, so one's epilogue / barrier / prologue sits under the other's MFMAs.
+// Tile shares (both shapes): 64-column layers -- wave & 3 = column tile, 7 row tiles from 6 * (wave >> 2) (with 8 waves the two
+// halves both compute tile 6); 32-column layers -- wave & 1 = column tile, three row tiles from 3 * (wave >> 1) plus a 1/NSPLIT
+// share of the k-range of the last tile MT - 1.
+template <int NBv, int NWv>
+struct Cfg {
+    static constexpr int NB = NBv, NW = NWv, NTH = NWv * 64, ROWS = NBv * 25, MT = (NBv * 25 + 15) / 16;
+    static constexpr int NSPLIT = NWv / 2;                       // waves sharing the k-range of tile MT - 1 of a 32-column layer
+    static constexpr int PADROWS = PAD0 + NBv * PADPOS + 1;
+    static constexpr int INROWS = NBv * 49 + 56;                 // staged input planes + what padding rows / the zero-weight 10th tap reach
+    static constexpr int NTW = (19 + NWv - 1) / NWv;             // policy dense: column tiles per wave
+    static_assert(MT - 1 == 3 * NSPLIT && MT <= 13 && (NWv == 4 || NWv == 8), "tile shares assume 3 full row tiles per wave");
 };
-static_assert(INROWS * LDI <= PADROWS * LDY, "the staged input planes alias y1");
-static_assert(sizeof(Smem) + 2 * 7800 <= 160 * 1024, "one evaluator workgroup per CU plus room for two tree-kernel workgroups");
+
+template <typename C>
+struct Smem {
+    float x[C::MT * 16 * LDX];           // 64-channel trunk activations
+    float y1[C::PADROWS * LDY];          // 32-channel 1x1 output = 3x3 input, zero halo; the stem's input planes and the policy
+                                         // conv output alias it
+    float y2[C::MT * 16 * LDY];          // 32-channel 3x3 output; logits / value scratch alias it
+    float part[2][C::NSPLIT][256];       // partial sums of the k-split last row tile of the 32-column layers
+    static_assert(C::INROWS * LDI <= C::PADROWS * LDY, "the staged input planes alias y1");
+    static_assert(C::MT * 16 * 16 <= C::PADROWS * LDY, "the policy conv output aliases y1");
+    static_assert(256 + C::NB * (NPOL_PAD + 32) <= C::MT * 16 * LDY, "logits and value scratch alias y2");
+};
+static_assert(sizeof(Smem<Cfg<8, 8>>) + 2 * 7800 <= 160 * 1024, "<8,8>: one evaluator workgroup per CU plus two tree-kernel workgroups");
+static_assert(2 * sizeof(Smem<Cfg<4, 4>>) + 7800 <= 160 * 1024, "<4,4>: two evaluator workgroups per CU plus a tree-kernel workgroup");
 
 // the packed weights as a buffer resource: loads take a scalar byte offset (+ the lane's 16 bytes), no vector address math
 struct WBuf {
@@ -174,16 +188,21 @@ __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, in
 // 32 slots duplicated, four phantom), a wave takes THREE full row tiles of its column tile and a quarter of the
 // k-range of row tile 12 (xmt) of the same column tile -- same weight stream, 3.25 jobs' worth of MFMAs instead of
 // 4.  The quarter's raw sums go to Smem::part and are added up in a fixed order after the layer's barrier.
-template <int NMT, int KB, typename AFrag, typename Next, typename Epi>
+// EVERY output of these layers -- full tiles too -- is the fixed-order sum ((c0 + c1) + c2) + c3 of NSPLIT accumulation chains
+// over the NSPLIT segments of the k-range, so that a row's arithmetic does not depend on which tile (hence which slot of the
+// batch) it sits in: an evaluation is a function of the position alone, whatever the batch size, the slot or the sharding.
+template <int NMT, int KB, int NSPLIT, typename AFrag, typename Next, typename Epi>
 __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart, f32x4 (&pre)[NPREMAX],
                                                  AFrag afrag, Next next, Epi epi, float *part /* [256] of this (nt, kpart) */) {
     constexpr int NPRE = Pre<KB>::N;
     constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;
     const int lane = threadIdx.x & 63;
-    const int kb0 = (KB * kpart) >> 2, kb1 = (KB * (kpart + 1)) >> 2;
-    f32x4 acc[NMT], accx = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kb0 = (KB * kpart) / NSPLIT, kb1 = (KB * (kpart + 1)) / NSPLIT;
+    f32x4 acc[NMT][NSPLIT], accx = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NMT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NMT; i++)
+#pragma unroll
+        for (int c = 0; c < NSPLIT; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int w0 = wbase + nt * KB * 256;
     f32x4 bq[PB];
 #pragma unroll
@@ -194,6 +213,9 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
     a[0][NMT] = afrag(xmt, 0, NMT);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
+        int seg = 0;                                                    // the segment k-block kb belongs to (static after unrolling)
+#pragma unroll
+        for (int c = 1; c < NSPLIT; c++) seg += kb >= (KB * c) / NSPLIT ? 1 : 0;
         if (kb + 1 < KB) {
 #pragma unroll
             for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
@@ -205,7 +227,7 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < NMT; i++)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i], 0, 0, 0);   // D^T: see tile_out
+                acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
         }
         if ((kb >= kb0) & (kb < kb1)) {                                 // wave-uniform: ONE scalar branch per k-block
 #pragma unroll
@@ -214,24 +236,34 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
     }
     next();
 #pragma unroll
-    for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i]);
+    for (int i = 0; i < NMT; i++) {
+        f32x4 sum = acc[i][0];
+#pragma unroll
+        for (int c = 1; c < NSPLIT; c++) sum = sum + acc[i][c];          // the order reduce_split_tile uses for the shared tile
+        epi(mt0 + i, sum);
+    }
     *reinterpret_cast<f32x4 *>(&part[lane * 4]) = accx;                 // D-fragment order: [lane][reg]
 }
 
 // ReLU as ONE instruction (v_med3_f32 v, 0, +inf): `v > 0 ? v : 0` costs a canonicalising v_max plus the v_max itself
 __device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
 
-// after the barrier: row tile 12 of a 32-column layer = ((part0 + part1) + part2) + part3 + bias, ReLU
-template <bool PADDED>
-__device__ __forceinline__ void reduce_split_tile(const float (*part)[4][256], float bias /* of this thread's column, loaded before the layer */, float *y, int xmt) {
-    const int tid = threadIdx.x;
-    if (tid < 512) {
-        const int nt = tid >> 8, e = tid & 255, lane = e >> 2, reg = e & 3;
-        const int row = xmt * 16 + (lane & 15), col = nt * 16 + 4 * (lane >> 4) + reg;      // transposed fragment (tile_out)
-        const float v = ((part[nt][0][e] + part[nt][1][e]) + part[nt][2][e]) + part[nt][3][e] + bias;
+// after the barrier: the last row tile of a 32-column layer = (((part0 + part1) + part2) + part3) + bias, ReLU (fixed order);
+// thread handles entries tid, tid + NTH, ... of the 2 x 256; bias[i] = bias of entry i's column, loaded before the layer
+template <bool PADDED, typename C>
+__device__ __forceinline__ void reduce_split_tile(const float (*part)[C::NSPLIT][256], const float (&bias)[512 / C::NTH], float *y) {
+#pragma unroll
+    for (int i = 0; i < 512 / C::NTH; i++) {
+        const int idx = threadIdx.x + i * C::NTH;
+        const int nt = idx >> 8, e = idx & 255, lane = e >> 2, reg = e & 3;
+        const int row = (C::MT - 1) * 16 + (lane & 15), col = nt * 16 + 4 * (lane >> 4) + reg;      // transposed fragment (tile_out)
+        float v = part[nt][0][e];
+#pragma unroll
+        for (int k = 1; k < C::NSPLIT; k++) v = v + part[nt][k][e];
+        v = v + bias[i];
         if (PADDED) {                                                       // 3x3 input: interior cell of the zero-halo copy
             const int sp = row / 25, pos = row % 25;
-            if (row < ROWS) y[(PAD0 + sp * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + col] = relu(v);
+            if (row < C::ROWS) y[(PAD0 + sp * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + col] = relu(v);
         } else {
             y[row * LDY + col] = relu(v);
         }
@@ -260,13 +292,14 @@ __device__ unsigned long long net_stamps[64];
 #define NET_STAMP(i) do { } while (0)
 #endif
 
-constexpr int NTH = 512;                 // 8 waves per workgroup = 2 per SIMD (one workgroup per CU: 133 KB of LDS)
-
-__global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restrict__ W, const float *__restrict__ planes, int n,
-                                                          float *__restrict__ logits_out, double *__restrict__ p_out,
-                                                          float *__restrict__ v_out) {
+template <typename C>
+__global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__restrict__ W, const float *__restrict__ planes, int n,
+                                                             float *__restrict__ logits_out, double *__restrict__ p_out,
+                                                             float *__restrict__ v_out) {
+    constexpr int NB = C::NB, NTH = C::NTH, ROWS = C::ROWS, MT = C::MT, NSPLIT = C::NSPLIT, PADROWS = C::PADROWS, INROWS = C::INROWS,
+                  NW = C::NW, NTW = C::NTW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem &S = *reinterpret_cast<Smem *>(smem_raw);
+    Smem<C> &S = *reinterpret_cast<Smem<C> *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in an SGPR: tile choices and k-ranges become scalar branches
     const int q = lane >> 4, l15 = lane & 15;
@@ -290,7 +323,8 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
 #endif
 
     const int nt2 = wave & 1, qr = wave >> 1, mt3 = 3 * qr;      // this wave's share of the 32-column layers (see below)
-    const int rcol = (tid >> 8) * 16 + 4 * ((tid & 255) >> 6) + (tid & 3);   // the column this thread finishes in reduce_split_tile
+    // the columns whose k-split sums this thread finishes in reduce_split_tile (entries tid, tid + NTH, ... of 2 x 256)
+    auto rcol = [&](int i) { const int idx = tid + i * NTH; return (idx >> 8) * 16 + 4 * ((idx & 255) >> 6) + (idx & 3); };
     f32x4 pre[NPREMAX];                                          // the next layer's first weight k-blocks, in flight across barriers
     auto bias4 = [&](int off) -> f32x4 { return *reinterpret_cast<const f32x4 *>(W + off + 4 * q); };   // this lane's four output channels
     auto relu4 = [](const f32x4 &v) -> f32x4 { return f32x4{relu(v[0]), relu(v[1]), relu(v[2]), relu(v[3])}; };
@@ -337,8 +371,8 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     int a3[4], prow[3];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        int row = (i < 3 ? mt3 + i : 12) * 16 + l15;
-        if (row >= ROWS) row -= 25;                            // phantom rows of tile 12: any valid cell (results never read)
+        int row = (i < 3 ? mt3 + i : MT - 1) * 16 + l15;
+        if (row >= ROWS) row -= 25;                            // padding rows of the last tile: any valid cell (results never read)
         const int s = row / 25, pos = row % 25;
         a3[i] = (s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;              // = cell (r - 1, c - 1): PAD0 - 7 = 0
     }
@@ -350,23 +384,24 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     }
 
     // ---- nine bottleneck residual blocks (model.py:120-145) ------------------------------------------
-    float rbias;
+    float rbias[512 / NTH];
     for (int blk = 0; blk < 9; blk++) {
         {   // 1x1 64 -> 32: 2 column tiles x 4 row groups of three tiles + a quarter of tile 12's k-range each
             auto afrag = [&](int mt, int kb, int) -> f32x4 {
                 return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
             };
             const f32x4 bv = bias4(LAY.l1_b[blk] + nt2 * 16);
-            rbias = W[LAY.l1_b[blk] + rcol];
+#pragma unroll
+            for (int i = 0; i < 512 / NTH; i++) rbias[i] = W[LAY.l1_b[blk] + rcol(i)];
             auto epi = [&](int mt, const f32x4 &acc) {
                 const int i = mt - mt3;
                 *reinterpret_cast<f32x4 *>(&S.y1[(i == 0 ? prow[0] : (i == 1 ? prow[1] : prow[2])) + nt2 * 16]) = relu4(acc + bv);
             };
-            gemm_tiles_split<3, 4>(wb, LAY.l1_w[blk], nt2, mt3, 12, qr, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); }, epi,
+            gemm_tiles_split<3, 4, NSPLIT>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, qr, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); }, epi,
                                    S.part[nt2][qr]);
         }
         __syncthreads();
-        reduce_split_tile<true>(S.part, rbias, S.y1, 12);
+        reduce_split_tile<true, C>(S.part, rbias, S.y1);
         __syncthreads();
         NET_STAMP(2 + 3 * blk);
         {   // 3x3 same 32 -> 32: k-block kb = tap (kb >> 1), channels 16 (kb & 1) ..; the halo supplies the zeros
@@ -375,11 +410,12 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
                 return *reinterpret_cast<const f32x4 *>(&S.y1[a3[i] + ((tap / 3) * 6 + tap % 3) * LDY + (kb & 1) * 16]);
             };
             const f32x4 bv = bias4(LAY.l2_b[blk] + nt2 * 16);
-            rbias = W[LAY.l2_b[blk] + rcol];
+#pragma unroll
+            for (int i = 0; i < 512 / NTH; i++) rbias[i] = W[LAY.l2_b[blk] + rcol(i)];
             auto epi = [&](int mt, const f32x4 &acc) {
                 *reinterpret_cast<f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + nt2 * 16 + 4 * q]) = relu4(acc + bv);
             };
-            gemm_tiles_split<3, 18>(wb, LAY.l2_w[blk], nt2, mt3, 12, qr, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
+            gemm_tiles_split<3, 18, NSPLIT>(wb, LAY.l2_w[blk], nt2, mt3, MT - 1, qr, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
                                     S.part[nt2][qr]);
             NET_STAMP(32 + blk);                             // diagnostic: wave 0 done with its share of the 3x3 layer
 #ifdef CCSP_STAMPS
@@ -390,7 +426,7 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
 #endif
         }
         __syncthreads();
-        reduce_split_tile<false>(S.part, rbias, S.y2, 12);
+        reduce_split_tile<false, C>(S.part, rbias, S.y2);
         __syncthreads();
         NET_STAMP(3 + 3 * blk);
         {   // 1x1 32 -> 64 + residual: 4 column tiles x 2 row halves; the accumulators START from bias + block input
@@ -416,7 +452,7 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     // ---- policy head: 1x1 64 -> 16 (+ReLU) into pc[row][16] (contiguous = [position][400]), aliasing y1 ----
     float *pc = S.y1;                                    // [208][16] floats; only rows < 200 are read
     {
-        const int mt0 = wave < 6 ? 2 * wave : 11;            // two tiles per wave; waves 6 and 7 both take tiles 11, 12 (plain stores)
+        const int mt0 = 2 * wave < MT - 2 ? 2 * wave : MT - 2;   // two tiles per wave; the last waves share the last two (plain stores)
         auto afrag = [&](int mt, int kb, int) -> f32x4 {
             return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
         };
@@ -441,49 +477,49 @@ __global__ __launch_bounds__(NTH) void net_forward_kernel(const float *__restric
     NET_STAMP(29);
 
     // ---- policy dense 400 -> 294: M = positions (one 16-row tile, rows >= NB are zero), 19 column tiles ---
-    // A wave owns column tiles wave, wave + 8, wave + 16 and runs them TOGETHER: one A fragment per k-block feeds
+    // A wave owns column tiles wave, wave + NW, wave + 2 NW ... and runs them TOGETHER: one A fragment per k-block feeds
     // three independent accumulators, and the weights (470 KB, streamed from L2 by every workgroup) are fetched
     // two k-blocks ahead on three streams -- with one tile at a time the layer waited for one load per 4 MFMAs.
     {
         constexpr int PD = 2, KBP = 25;
         const float *bias = W + LAY.pf_b;
-        const f32x4 *bp[3];
-        bool valid[3];
+        const f32x4 *bp[NTW];
+        bool valid[NTW];
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int nt = wave + 8 * i;
+        for (int i = 0; i < NTW; i++) {
+            const int nt = wave + NW * i;
             valid[i] = nt < 19;
             bp[i] = reinterpret_cast<const f32x4 *>(W + LAY.pf_w) + (size_t)(valid[i] ? nt : 0) * KBP * 64 + lane;
         }
-        f32x4 acc[3], bq[PD][3];
+        f32x4 acc[NTW], bq[PD][NTW];
 #pragma unroll
-        for (int i = 0; i < 3; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NTW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < PD; d++)
 #pragma unroll
-            for (int i = 0; i < 3; i++) bq[d][i] = bp[i][(size_t)d * 64];
+            for (int i = 0; i < NTW; i++) bq[d][i] = bp[i][(size_t)d * 64];
         const float *arow = &pc[(l15 < NB ? l15 : 0) * 400 + 4 * q];
         for (int kb = 0; kb < KBP; kb++) {
             f32x4 a = *reinterpret_cast<const f32x4 *>(arow + kb * 16);
             if (l15 >= NB) a = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 bn[3];
+            f32x4 bn[NTW];
             const int kn = kb + PD < KBP ? kb + PD : KBP - 1;
 #pragma unroll
-            for (int i = 0; i < 3; i++) bn[i] = bp[i][(size_t)kn * 64];
+            for (int i = 0; i < NTW; i++) bn[i] = bp[i][(size_t)kn * 64];
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int i = 0; i < 3; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bq[0][i][j], acc[i], 0, 0, 0);
+                for (int i = 0; i < NTW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bq[0][i][j], acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
+            for (int i = 0; i < NTW; i++) {
 #pragma unroll
                 for (int d = 0; d + 1 < PD; d++) bq[d][i] = bq[d + 1][i];
                 bq[PD - 1][i] = bn[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int nt = wave + 8 * i;
+        for (int i = 0; i < NTW; i++) {
+            const int nt = wave + NW * i;
             if (valid[i])
                 for_each_out(0, acc[i], [&](int row, int col, float v) {
                     if (row < NB) lg[row * NPOL_PAD + nt * 16 + col] = v + bias[nt * 16 + col];
@@ -551,6 +587,24 @@ void pack_gemm(const std::vector<float> &Wkn, int K, int N, int KB, int NT, floa
 
 }  // namespace
 
+template <typename C>
+static int launch_net(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream, bool *attr_set) {
+    // the dynamic-LDS opt-in is a per-device property of the kernel: once per device ordinal, not per process
+    int dev = 0;
+    CCSP_HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        CCSP_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(net_forward_kernel<C>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<C>)));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const int grid = (n + C::NB - 1) / C::NB;
+    hipLaunchKernelGGL(net_forward_kernel<C>, dim3(grid), dim3(C::NTH), sizeof(Smem<C>), (hipStream_t)stream, packed, planes, n, logits, p, v);
+    CCSP_HIPCHK(hipGetLastError());
+    return CCSP_OK;
+}
+
+static int g_net_shape = CCSP_NET_SHAPE;      // positions per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
+
 extern "C" {
 
 int ccsp_net_plain_size(void) { return PLAIN_TOTAL; }
@@ -597,22 +651,19 @@ int ccsp_net_pack(const float *plain, float *packed) {
 
 // Device: Model.predict (model.py:21-24) for a batch.  packed: device copy of ccsp_net_pack's output; planes
 // [n][7][7][7] f32; logits [n][294] f32 (or NULL); p [n][294] f64 softmax (or NULL); v [n] f32.
+// Test / measurement hook: pick the workgroup shape of ccsp_net_forward (8 or 4 positions per workgroup; anything else
+// restores the default).  Both shapes compute every position with the same arithmetic in the same order: results are identical.
+int ccsp_debug_net_shape(int positions_per_workgroup) {
+    g_net_shape = (positions_per_workgroup == 4 || positions_per_workgroup == 8) ? positions_per_workgroup : CCSP_NET_SHAPE;
+    return g_net_shape;
+}
+
 int ccsp_net_forward(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream) {
     if (n < 0 || (n > 0 && (!packed || !planes || !v))) return CCSP_EINVAL;
     if (n == 0) return CCSP_OK;
-    // the 133 KB dynamic-LDS opt-in is a per-device property of the kernel: once per device ordinal, not per process
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    CCSP_HIPCHK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        CCSP_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(net_forward_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
-    const int grid = (n + NB - 1) / NB;
-    hipLaunchKernelGGL(net_forward_kernel, dim3(grid), dim3(NTH), sizeof(Smem), (hipStream_t)stream, packed, planes, n, logits, p, v);
-    CCSP_HIPCHK(hipGetLastError());
-    return CCSP_OK;
+    static bool attr8[64] = {false}, attr4[64] = {false};
+    if (g_net_shape == 4) return launch_net<Cfg<4, 4>>(packed, planes, n, logits, p, v, stream, attr4);
+    return launch_net<Cfg<8, 8>>(packed, planes, n, logits, p, v, stream, attr8);
 }
 
 #ifdef CCSP_STAMPS

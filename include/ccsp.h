@@ -237,6 +237,10 @@ int ccsp_net_pack(const float *plain, float *packed);
  * packed = device copy of ccsp_net_pack's output. */
 int ccsp_net_forward(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream);
 
+/* test / measurement hook: workgroup shape of ccsp_net_forward -- 8 positions per workgroup (one workgroup per CU) or 4 (two per
+ * CU); other values restore the default.  Same results either way.  Returns the value in force. */
+int ccsp_debug_net_shape(int positions_per_workgroup);
+
 /* ---- read-back (synchronous; host buffers unless said otherwise) ----------------------------------- */
 int ccsp_read_counters(ccsp_ctx *ctx, uint64_t *out /* [CCSP_CNT_COUNT] */);
 int ccsp_read_visit_histogram(ccsp_ctx *ctx, uint64_t *out /* [294]: sum of root visit counts per action */);

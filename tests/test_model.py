@@ -187,6 +187,41 @@ def test_float32_distances(net, golden_dir):
 
 
 @pytest.mark.gpu
+def test_gpu_evaluation_is_a_function_of_the_position_alone(net, golden_dir):
+    """an evaluation must not depend on the batch size, on the position's slot in the batch, or on the workgroup's row tile
+    the position's rows fall into (the k-split tile included): the same 3 positions at every slot of batches of several
+    sizes, for both workgroup shapes of the fused kernel -- every copy bit-identical"""
+    import torch
+    from chinesecheckersagent_amd import _lib
+    from chinesecheckersagent_amd.model import ResidualCNN
+    L = _lib.lib()
+    m = ResidualCNN(device='cuda', backend='hip')
+    m.load_weights(golden_dir + '/good_model.h5')
+    base = torch.from_numpy(net['planes'][:3].astype(np.float32)).cuda()
+    ref64 = net['logits_good_model'][:3]
+    try:
+        for shape in (8, 4):
+            assert L.ccsp_debug_net_shape(shape) == shape
+            want = None
+            for n in (3, 16, 19, 51):
+                idx = torch.arange(n, device='cuda') % 3
+                lg, v = m.predict_batch(base[idx].contiguous())
+                p, _ = m.evaluate_batch(base[idx].contiguous())
+                for k in range(3):
+                    rows = (idx == k).nonzero().flatten()
+                    if want is None:
+                        want = [None, None, None]
+                    if want[k] is None:
+                        want[k] = (lg[rows[0]].clone(), v[rows[0]].clone(), p[rows[0]].clone())
+                    for r in rows:
+                        assert torch.equal(lg[r], want[k][0]) and torch.equal(v[r], want[k][1]) and torch.equal(p[r], want[k][2]), (shape, n, int(r))
+            d = np.abs(torch.stack([w[0] for w in want]).double().cpu().numpy() - ref64)
+            assert d.max() < FP32_CAP
+    finally:
+        L.ccsp_debug_net_shape(0)
+
+
+@pytest.mark.gpu
 def test_gpu_float32_distances(net, golden_dir):
     """the fused HIP kernel against the float64 AND the float32 restatements, numbers written out for DESIGN.md"""
     import json
