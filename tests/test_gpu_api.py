@@ -78,11 +78,41 @@ def test_selfplay_with_the_net(golden_dir):
     st2, meta2, pi2 = b2.eng.log()
     b2.close()
     # the opening is a function of (seed, game id) only: the first searched position of games 1 and 2 is the
-    # same in both batches.  (Later plies depend on net outputs, which batched GEMMs may round differently
-    # for different batch sizes -- the tree is chaotic in its priors)
+    # same in both batches (the whole records are, too: test_sharding_independence_with_the_net)
     first = {int(meta['game'][i]): st[i].tobytes() for i in range(len(meta)) if int(meta['ply'][i]) == 6}
     first2 = {int(meta2['game'][i]): st2[i].tobytes() for i in range(len(meta2)) if int(meta2['ply'][i]) == 6}
     assert first2 == {g: first[g] for g in (1, 2)}
+
+
+def test_sharding_independence_with_the_net(golden_dir):
+    """the fused evaluator is a function of the position alone (tests/test_model.py), so with the NET, too, a game's whole
+    record -- every searched position and pi, bit for bit -- is the same whichever batch, slot or shard plays it: 11 games
+    in one context == the same ids over two strided contexts (a rank of 2 each) == one game alone"""
+    from chinesecheckersagent_amd import selfplay as sp
+    from chinesecheckersagent_amd.model import ResidualCNN
+    m = ResidualCNN()
+    m.load_weights(golden_dir + '/good_model.h5')
+    seed, sims, plies = 9, 24, 14
+
+    def run(n_slots, first, stride):
+        b = sp.BatchSelfPlay(m, n_slots=n_slots, sims=sims, seed=seed, first_game=first, game_stride=stride, max_games=n_slots,
+                             log_capacity=n_slots * 64)
+        for _ in range(plies):
+            b.play_ply()
+        st, meta, pi = b.eng.log()
+        assert b.eng.counters()['errors'] == 0
+        b.close()
+        out = {}
+        for i in np.lexsort((meta['ply'], meta['game'])):
+            out.setdefault(int(meta['game'][i]), []).append((int(meta['ply'][i]), st[i].tobytes(), pi[i].tobytes()))
+        return out
+    whole = run(11, 100, 1)
+    assert len(whole) == 11 and all(len(v) == plies - 6 for v in whole.values())
+    shards = {}
+    shards.update(run(6, 100, 2))
+    shards.update(run(5, 101, 2))
+    assert shards == whole
+    assert run(1, 107, 1)[107] == whole[107]
 
 
 def test_generate_self_play_signature(golden_dir):
