@@ -259,10 +259,18 @@ def test_restart_budget_log_overflow_and_odd_sizes(eng):
     assert c['samples'] == len(meta) == int(res['n_samples'].sum())
     assert c['plies'] == int(res['n_plies'].sum())
     e.close()
-    # every game once more, one per context: same results (restart order does not matter)
-    for k in (0, 6):
+    # every game against the oracle playing it alone: restart order and the fast-forwarded openings of restarted games
+    # (their six random plies are played in the call that starts them) change no game's record
+    by_game = {}
+    for i in np.lexsort((meta['ply'], meta['game'])):
+        by_game.setdefault(int(meta['game'][i]), []).append(i)
+    for k in range(7):
         o = orc.selfplay(77, 10 + 3 * k, 4, 1)
         assert o['status'] == int(res['status'][k]) and len(o['plies']) == int(res['n_plies'][k])
+        rows = by_game[10 + 3 * k]
+        assert [int(meta['ply'][r]) for r in rows] == list(range(6, 6 + len(rows))) and len(rows) == int(res['n_samples'][k])
+        if len(o['pi']):                                   # the oracle hands back the history of won games only
+            assert len(rows) == len(o['pi']) and all(np.array_equal(pi[r], o['pi'][j]) for j, r in enumerate(rows))
     # log too small: 2 rows for 5 slots
     e = eng.SelfPlayEngine(n_slots=5, sims=4, seed=1, max_games=5, log_capacity=2)
     e.play_plies(_lib.EVAL_UNIFORM, 8)
