@@ -112,7 +112,10 @@ struct Params {
     int greedy, gen, stuck_limit;                   // next-4: GreedyPlayer seats (CCSP_GREEDY_*), data-generator mode, its ply cap
 };
 
-constexpr int RCP_N = 512;          // reciprocal table entries kept in LDS by the fused simulation kernel
+constexpr int RCP_N = 422;          // reciprocal table entries kept in LDS by the fused simulation kernel: searches of up to 420
+                                    // simulations (BASELINE's 400) divide through it; 422 doubles = the 3376 bytes the ply-end data of
+                                    // the same union needs, so that the per-wave LDS stays at 6.9 KB and THREE tree-kernel workgroups
+                                    // fit beside an evaluator workgroup (ccsp_net.hip)
 
 struct Lds {                      // per-wave scratch (one wave per workgroup)
     ccsp_line_tables T;           // line tables (ccsp_rules.h), copied from device constant data

@@ -109,7 +109,7 @@ struct Smem {
     static_assert(C::MT * 16 * 16 <= C::PADROWS * LDY, "the policy conv output aliases y1");
     static_assert(256 + C::NB * (NPOL_PAD + 32) <= C::MT * 16 * LDY, "logits and value scratch alias y2");
 };
-static_assert(sizeof(Smem<Cfg<8, 8>>) + 2 * 7800 <= 160 * 1024, "<8,8>: one evaluator workgroup per CU plus two tree-kernel workgroups");
+static_assert(sizeof(Smem<Cfg<8, 8>>) + 3 * 6900 <= 160 * 1024, "<8,8>: one evaluator workgroup per CU plus three tree-kernel workgroups");
 static_assert(2 * sizeof(Smem<Cfg<4, 4>>) + 7800 <= 160 * 1024, "<4,4>: two evaluator workgroups per CU plus a tree-kernel workgroup");
 
 // the packed weights as a buffer resource: loads take a scalar byte offset (+ the lane's 16 bytes), no vector address math
