@@ -476,54 +476,55 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     __syncthreads();
     NET_STAMP(29);
 
-    // ---- policy dense 400 -> 294: M = positions (one 16-row tile, rows >= NB are zero), 19 column tiles ---
-    // A wave owns column tiles wave, wave + NW, wave + 2 NW ... and runs them TOGETHER: one A fragment per k-block feeds
-    // three independent accumulators, and the weights (470 KB, streamed from L2 by every workgroup) are fetched
-    // two k-blocks ahead on three streams -- with one tile at a time the layer waited for one load per 4 MFMAs.
+    // ---- policy dense 400 -> 294: 19 column tiles, the positions are the MFMA's second operand ----------------------
+    // A wave owns column tiles wave, wave + NW, wave + 2 NW ... and runs them TOGETHER: one activation fragment per
+    // k-block feeds NTW independent accumulators, and the weights (470 KB, streamed from L2 by every workgroup) come through
+    // scalar-addressed buffer loads two k-blocks ahead.  Transposed like the other layers (tile_out): a lane holds four
+    // consecutive logits of ONE position, and since a position's column of the product depends on that position's
+    // activations only, the lanes of the unused columns (positions >= NB of the 16) simply re-read a real position --
+    // no zero rows, no masks in the loop.  A tile past the 19th (a wave's last share may be empty) is skipped by one scalar
+    // branch per k-block.
     {
-        constexpr int PD = 2, KBP = 25;
-        const float *bias = W + LAY.pf_b;
-        const f32x4 *bp[NTW];
+        constexpr int KBP = 25, PD = 3;                              // ring of PD slots: PD - 1 k-blocks in flight
+        int woff[NTW];
         bool valid[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
             const int nt = wave + NW * i;
             valid[i] = nt < 19;
-            bp[i] = reinterpret_cast<const f32x4 *>(W + LAY.pf_w) + (size_t)(valid[i] ? nt : 0) * KBP * 64 + lane;
+            woff[i] = LAY.pf_w + (valid[i] ? nt : 0) * KBP * 256;
         }
         f32x4 acc[NTW], bq[PD][NTW];
 #pragma unroll
         for (int i = 0; i < NTW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int d = 0; d < PD; d++)
+        for (int d = 0; d + 1 < PD; d++)
 #pragma unroll
-            for (int i = 0; i < NTW; i++) bq[d][i] = bp[i][(size_t)d * 64];
-        const float *arow = &pc[(l15 < NB ? l15 : 0) * 400 + 4 * q];
+            for (int i = 0; i < NTW; i++) bq[d][i] = wb.load(woff[i] + d * 256);
+        const float *arow = &pc[(l15 & (NB - 1)) * 400 + 4 * q];
+        f32x4 a[2];
+        a[0] = *reinterpret_cast<const f32x4 *>(arow);
+#pragma unroll
         for (int kb = 0; kb < KBP; kb++) {
-            f32x4 a = *reinterpret_cast<const f32x4 *>(arow + kb * 16);
-            if (l15 >= NB) a = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 bn[NTW];
-            const int kn = kb + PD < KBP ? kb + PD : KBP - 1;
+            if (kb + 1 < KBP) a[(kb + 1) & 1] = *reinterpret_cast<const f32x4 *>(arow + (kb + 1) * 16);
+            if (kb + PD - 1 < KBP) {
 #pragma unroll
-            for (int i = 0; i < NTW; i++) bn[i] = bp[i][(size_t)kn * 64];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int i = 0; i < NTW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bq[0][i][j], acc[i], 0, 0, 0);
+                for (int i = 0; i < NTW; i++) bq[(kb + PD - 1) % PD][i] = wb.load(woff[i] + (kb + PD - 1) * 256);
+            }
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
+                if (i + 1 < NTW || valid[i]) {                          // only a wave's LAST tile can be empty
 #pragma unroll
-                for (int d = 0; d + 1 < PD; d++) bq[d][i] = bq[d + 1][i];
-                bq[PD - 1][i] = bn[i];
+                    for (int j = 0; j < 4; j++)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[kb % PD][i][j], a[kb & 1][j], acc[i], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
             const int nt = wave + NW * i;
-            if (valid[i])
-                for_each_out(0, acc[i], [&](int row, int col, float v) {
-                    if (row < NB) lg[row * NPOL_PAD + nt * 16 + col] = v + bias[nt * 16 + col];
-                });
+            if (valid[i] && l15 < NB)
+                *reinterpret_cast<f32x4 *>(&lg[l15 * NPOL_PAD + nt * 16 + 4 * q]) = acc[i] + bias4(LAY.pf_b + nt * 16);
         }
     }
     // ---- value head, part 2: dense 25 -> 32 ReLU (thread = (position, unit)), then 32 -> 1 tanh ---------
