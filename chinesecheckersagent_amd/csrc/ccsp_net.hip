@@ -410,8 +410,6 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 return *reinterpret_cast<const f32x4 *>(&S.y1[a3[i] + ((tap / 3) * 6 + tap % 3) * LDY + (kb & 1) * 16]);
             };
             const f32x4 bv = bias4(LAY.l2_b[blk] + nt2 * 16);
-#pragma unroll
-            for (int i = 0; i < 512 / NTH; i++) rbias[i] = W[LAY.l2_b[blk] + rcol(i)];
             auto epi = [&](int mt, const f32x4 &acc) {
                 *reinterpret_cast<f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + nt2 * 16 + 4 * q]) = relu4(acc + bv);
             };
@@ -426,12 +424,25 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
 #endif
         }
         __syncthreads();
-        reduce_split_tile<false, C>(S.part, rbias, S.y2);
-        __syncthreads();
         NET_STAMP(3 + 3 * blk);
-        {   // 1x1 32 -> 64 + residual: 4 column tiles x 2 row halves; the accumulators START from bias + block input
+        {   // 1x1 32 -> 64 + residual: 4 column tiles x 2 row halves
             const int nt = wave & 3, half = wave >> 2, mt0 = half * 6;       // tiles 0-6 and 6-12: tile 6 is computed by both halves ...
-            auto afrag = [&](int mt, int kb, int) -> f32x4 {
+            // The 3x3 layer's k-split tile (MT - 1) is consumed straight from its partial sums -- no reduction pass, no two extra
+            // barriers: part[nt2][c][lane * 4 + j] is, for THIS lane's (row, k-slot), exactly what an activation fragment of
+            // k-block nt2 holds, so the waves whose share ends with that tile form ((c0 + c1) + c2) + c3 + bias, ReLU in registers.
+            const bool has_x = mt0 + 6 == MT - 1;                           // wave-uniform
+            f32x4 ax[2];
+            if (has_x) {
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) {
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(&S.part[kb][0][lane * 4]);
+#pragma unroll
+                    for (int c = 1; c < NSPLIT; c++) v = v + *reinterpret_cast<const f32x4 *>(&S.part[kb][c][lane * 4]);
+                    ax[kb] = relu4(v + bias4(LAY.l2_b[blk] + kb * 16));
+                }
+            }
+            auto afrag = [&](int mt, int kb, int i) -> f32x4 {
+                if (i == 6 && has_x) return ax[kb];
                 return *reinterpret_cast<const f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + kb * 16 + 4 * q]);
             };
             const f32x4 bv = bias4(LAY.l3_b[blk] + nt * 16);
