@@ -1,8 +1,8 @@
 // ccsp_net.hip -- the policy/value network (graph of model.py:58-145) as ONE
 // fused HIP kernel for gfx950: a workgroup carries 8 positions through the whole network with every
 // activation resident in LDS, each layer an fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains,
-// the reference's own arithmetic type) GEMM whose B operand (weights, BatchNorm folded in at load time)
-// streams from L2 in a pre-packed per-lane order.  Replaces ~90 MIOpen/elementwise launches per forward.
+// the reference's own arithmetic type) GEMM whose weights (BatchNorm folded in at load time) stream from L2
+// in a pre-packed per-lane order.  Replaces ~90 MIOpen/elementwise launches per forward.
 //
 //   rows = position * 25 + (r * 5 + c)    (200 rows per workgroup, padded to 13 tiles of 16)
 //   stem   3x3 valid 7->64      : A = implicit im2col of the 7x7x7 planes      K = 9 taps x 8 (7 + zero pad)
@@ -14,9 +14,11 @@
 // Inner loops carry NO vector-ALU instruction besides the MFMAs: on gfx950 the fp32 MFMA shares the SIMD's fp32 lanes
 // with ordinary VALU work, and every v_cndmask / v_add between MFMAs was measured to cost 10-15 cycles of matrix pipe
 // (tools/probe/mfma_probe.hip: 99.7 % of the pipe on bare MFMAs, 67 % with one v_cndmask per MFMA).  Hence: the 3x3
-// layers read their input from a copy with a ZERO HALO (7x7 cells per position) instead of masking taps, weights come
-// through buffer loads whose addresses are scalar (SGPR offset + immediate), biases start the accumulators, and the
-// k-split's extra MFMAs sit behind one scalar branch per k-block.
+// layers read their input from a copy with a ZERO HALO instead of masking taps, weights come through buffer loads whose
+// addresses are scalar (SGPR offset + immediate), and the k-split's extra MFMAs sit behind one scalar branch per k-block.
+// The weights are the MFMA's FIRST operand (tile_out below): a lane ends up with four consecutive channels of one row.
+// An evaluation is a function of the position alone: every output is formed by the same chains in the same order
+// whatever the batch size, the slot in the batch or the row tile (gemm_tiles_split).
 //
 // Packed weight order of a GEMM layer with K = 16*KB, N = 16*NT:  [nt][kb][lane][j]  =
 // W[k = 16 kb + 4 (lane >> 4) + j][n = 16 nt + (lane & 15)]  -- one 16-byte load per lane per 16 k.
