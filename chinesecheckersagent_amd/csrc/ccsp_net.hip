@@ -241,36 +241,71 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
     for (int i = 0; i < NMT; i++) {
         f32x4 sum = acc[i][0];
 #pragma unroll
-        for (int c = 1; c < NSPLIT; c++) sum = sum + acc[i][c];          // the order reduce_split_tile uses for the shared tile
+        for (int c = 1; c < NSPLIT; c++) sum = sum + acc[i][c];          // the order in which the shared tile's partial sums are added up by its consumer
         epi(mt0 + i, sum);
     }
     *reinterpret_cast<f32x4 *>(&part[lane * 4]) = accx;                 // D-fragment order: [lane][reg]
 }
 
-// ReLU as ONE instruction (v_med3_f32 v, 0, +inf): `v > 0 ? v : 0` costs a canonicalising v_max plus the v_max itself
-__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
-
-// after the barrier: the last row tile of a 32-column layer = (((part0 + part1) + part2) + part3) + bias, ReLU (fixed order);
-// thread handles entries tid, tid + NTH, ... of the 2 x 256; bias[i] = bias of entry i's column, loaded before the layer
-template <bool PADDED, typename C>
-__device__ __forceinline__ void reduce_split_tile(const float (*part)[C::NSPLIT][256], const float (&bias)[512 / C::NTH], float *y) {
+// The same share-out for the SHORT 32-column layers (the blocks' first 1x1, K = 64): there a reduction pass and its two
+// barriers cost more than the imbalance they remove, so the last row tile is not k-split but computed whole -- by the wave of
+// each column tile whose share comes last (kpart == NSPLIT - 1), as NSPLIT chains like every other tile (same arithmetic).
+template <int NMT, int KB, int NSPLIT, typename AFrag, typename Next, typename Epi, typename EpiX>
+__device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart, f32x4 (&pre)[NPREMAX],
+                                                AFrag afrag, Next next, Epi epi, EpiX epix) {
+    constexpr int NPRE = Pre<KB>::N;
+    constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;
+    const bool mine = kpart == NSPLIT - 1;                              // wave-uniform
+    f32x4 acc[NMT + 1][NSPLIT];
 #pragma unroll
-    for (int i = 0; i < 512 / C::NTH; i++) {
-        const int idx = threadIdx.x + i * C::NTH;
-        const int nt = idx >> 8, e = idx & 255, lane = e >> 2, reg = e & 3;
-        const int row = (C::MT - 1) * 16 + (lane & 15), col = nt * 16 + 4 * (lane >> 4) + reg;      // transposed fragment (tile_out)
-        float v = part[nt][0][e];
+    for (int i = 0; i <= NMT; i++)
 #pragma unroll
-        for (int k = 1; k < C::NSPLIT; k++) v = v + part[nt][k][e];
-        v = v + bias[i];
-        if (PADDED) {                                                       // 3x3 input: interior cell of the zero-halo copy
-            const int sp = row / 25, pos = row % 25;
-            if (row < C::ROWS) y[(PAD0 + sp * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + col] = relu(v);
-        } else {
-            y[row * LDY + col] = relu(v);
+        for (int c = 0; c < NSPLIT; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int w0 = wbase + nt * KB * 256;
+    f32x4 bq[PB];
+#pragma unroll
+    for (int d = 0; d < NPRE; d++) bq[d] = pre[d];
+    f32x4 a[2][NMT + 1];
+#pragma unroll
+    for (int i = 0; i < NMT; i++) a[0][i] = afrag(mt0 + i, 0, i);
+    a[0][NMT] = afrag(xmt, 0, NMT);
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        int seg = 0;
+#pragma unroll
+        for (int c = 1; c < NSPLIT; c++) seg += kb >= (KB * c) / NSPLIT ? 1 : 0;
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
+            a[(kb + 1) & 1][NMT] = afrag(xmt, kb + 1, NMT);
+        }
+        if (kb + PB - 1 < KB && kb + PB - 1 >= NPRE) bq[(kb + PB - 1) % PB] = wb.load(w0 + (kb + PB - 1) * 256);
+        const f32x4 b = bq[kb % PB];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int i = 0; i < NMT; i++)
+                acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
+        }
+        if (mine) {                                                     // ONE scalar branch per k-block
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[NMT][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], acc[NMT][seg], 0, 0, 0);
         }
     }
+    next();
+#pragma unroll
+    for (int i = 0; i <= NMT; i++) {
+        f32x4 sum = acc[i][0];
+#pragma unroll
+        for (int c = 1; c < NSPLIT; c++) sum = sum + acc[i][c];
+        if (i < NMT) epi(mt0 + i, sum);
+        else if (mine) epix(sum);
+    }
 }
+
+// ReLU as ONE instruction (v_med3_f32 v, 0, +inf): `v > 0 ? v : 0` costs a canonicalising v_max plus the v_max itself
+__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
 
 // The layer GEMMs pass the WEIGHTS as the MFMA's first operand and the activations as its second: the instruction then
 // produces the transposed tile, and a lane holds, for ONE activation row (16 mt + (lane & 15)), FOUR CONSECUTIVE output
@@ -325,8 +360,6 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
 #endif
 
     const int nt2 = wave & 1, qr = wave >> 1, mt3 = 3 * qr;      // this wave's share of the 32-column layers (see below)
-    // the columns whose k-split sums this thread finishes in reduce_split_tile (entries tid, tid + NTH, ... of 2 x 256)
-    auto rcol = [&](int i) { const int idx = tid + i * NTH; return (idx >> 8) * 16 + 4 * ((idx & 255) >> 6) + (idx & 3); };
     f32x4 pre[NPREMAX];                                          // the next layer's first weight k-blocks, in flight across barriers
     auto bias4 = [&](int off) -> f32x4 { return *reinterpret_cast<const f32x4 *>(W + off + 4 * q); };   // this lane's four output channels
     auto relu4 = [](const f32x4 &v) -> f32x4 { return f32x4{relu(v[0]), relu(v[1]), relu(v[2]), relu(v[3])}; };
@@ -384,26 +417,30 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         const int s = row / 25, pos = row % 25;
         prow[i] = (PAD0 + s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;
     }
+    int prowx;                                                 // the same for this lane's row of the last tile (real rows: l15 < ROWS - 16 (MT - 1))
+    {
+        const int row = (MT - 1) * 16 + (l15 < ROWS - (MT - 1) * 16 ? l15 : 0);
+        const int s = row / 25, pos = row % 25;
+        prowx = (PAD0 + s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;
+    }
 
     // ---- nine bottleneck residual blocks (model.py:120-145) ------------------------------------------
-    float rbias[512 / NTH];
     for (int blk = 0; blk < 9; blk++) {
         {   // 1x1 64 -> 32: 2 column tiles x 4 row groups of three tiles + a quarter of tile 12's k-range each
             auto afrag = [&](int mt, int kb, int) -> f32x4 {
                 return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
             };
             const f32x4 bv = bias4(LAY.l1_b[blk] + nt2 * 16);
-#pragma unroll
-            for (int i = 0; i < 512 / NTH; i++) rbias[i] = W[LAY.l1_b[blk] + rcol(i)];
             auto epi = [&](int mt, const f32x4 &acc) {
                 const int i = mt - mt3;
                 *reinterpret_cast<f32x4 *>(&S.y1[(i == 0 ? prow[0] : (i == 1 ? prow[1] : prow[2])) + nt2 * 16]) = relu4(acc + bv);
             };
-            gemm_tiles_split<3, 4, NSPLIT>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, qr, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); }, epi,
-                                   S.part[nt2][qr]);
+            auto epix = [&](const f32x4 &acc) {                                 // the last tile: its real rows only
+                if (l15 < ROWS - (MT - 1) * 16) *reinterpret_cast<f32x4 *>(&S.y1[prowx + nt2 * 16]) = relu4(acc + bv);
+            };
+            gemm_tiles_last<3, 4, NSPLIT>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, qr, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); },
+                                          epi, epix);
         }
-        __syncthreads();
-        reduce_split_tile<true, C>(S.part, rbias, S.y1);
         __syncthreads();
         NET_STAMP(2 + 3 * blk);
         {   // 3x3 same 32 -> 32: k-block kb = tap (kb >> 1), channels 16 (kb & 1) ..; the halo supplies the zeros
