@@ -248,19 +248,18 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
 }
 
 // The same share-out for the SHORT 32-column layers (the blocks' first 1x1, K = 64): there a reduction pass and its two
-// barriers cost more than the imbalance they remove, so the last row tile is not k-split but computed whole -- by the wave of
-// each column tile whose share comes last (kpart == NSPLIT - 1), as NSPLIT chains like every other tile (same arithmetic).
+// barriers cost more than the imbalance they remove, so the last row tile is not k-split but computed whole by the wave of
+// each column tile whose share comes last (kpart == NSPLIT - 1).  No tile of these layers is split, so every output is one
+// plain accumulation chain over k -- the same arithmetic for every row without the segment sums of gemm_tiles_split.
 template <int NMT, int KB, int NSPLIT, typename AFrag, typename Next, typename Epi, typename EpiX>
 __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart, f32x4 (&pre)[NPREMAX],
                                                 AFrag afrag, Next next, Epi epi, EpiX epix) {
     constexpr int NPRE = Pre<KB>::N;
     constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;
     const bool mine = kpart == NSPLIT - 1;                              // wave-uniform
-    f32x4 acc[NMT + 1][NSPLIT];
+    f32x4 acc[NMT + 1];
 #pragma unroll
-    for (int i = 0; i <= NMT; i++)
-#pragma unroll
-        for (int c = 0; c < NSPLIT; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i <= NMT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int w0 = wbase + nt * KB * 256;
     f32x4 bq[PB];
 #pragma unroll
@@ -271,9 +270,6 @@ __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int n
     a[0][NMT] = afrag(xmt, 0, NMT);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
-        int seg = 0;
-#pragma unroll
-        for (int c = 1; c < NSPLIT; c++) seg += kb >= (KB * c) / NSPLIT ? 1 : 0;
         if (kb + 1 < KB) {
 #pragma unroll
             for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
@@ -285,23 +281,18 @@ __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int n
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < NMT; i++)
-                acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i], 0, 0, 0);   // D^T: see tile_out
         }
         if (mine) {                                                     // ONE scalar branch per k-block
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                acc[NMT][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], acc[NMT][seg], 0, 0, 0);
+                acc[NMT] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], acc[NMT], 0, 0, 0);
         }
     }
     next();
 #pragma unroll
-    for (int i = 0; i <= NMT; i++) {
-        f32x4 sum = acc[i][0];
-#pragma unroll
-        for (int c = 1; c < NSPLIT; c++) sum = sum + acc[i][c];
-        if (i < NMT) epi(mt0 + i, sum);
-        else if (mine) epix(sum);
-    }
+    for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i]);
+    if (mine) epix(acc[NMT]);
 }
 
 // ReLU as ONE instruction (v_med3_f32 v, 0, +inf): `v > 0 ? v : 0` costs a canonicalising v_max plus the v_max itself
