@@ -23,22 +23,15 @@ def _read(path):
 
 
 def combine_train_data(board_x, pi_y, v_y, first_version, last_version, save_dir, pref):
-    """the given samples (if any) plus the files '{save_dir}/{pref}{i}.h5' for i in first..last that exist
-    -> (board_x, pi_y, v_y, number of sources), or ([], [], [], 0)"""
-    bx, py, vy = [], [], []
-    if len(board_x) > 0 and len(pi_y) > 0 and len(v_y) > 0:
-        bx.append(np.asarray(board_x)); py.append(np.asarray(pi_y)); vy.append(np.asarray(v_y))
-    for i in range(first_version, last_version + 1):
-        if i < 0:
-            continue
-        filename = '{}/{}{}.h5'.format(save_dir, pref, i)
-        if not os.path.exists(filename):
-            continue
-        b, p, v = _read(filename)
-        bx.append(b); py.append(p); vy.append(v)
-    if bx:
-        return np.vstack(bx), np.vstack(py), np.hstack(vy), len(bx)
-    return [], [], [], 0
+    """the given samples (if all three are non-empty) plus the files '{save_dir}/{pref}{i}.h5', i = first..last (i >= 0), that
+    exist -> (board_x, pi_y, v_y, number of sources) as arrays, or ([], [], [], 0) when there is nothing"""
+    sources = [(np.asarray(board_x), np.asarray(pi_y), np.asarray(v_y))] if min(len(board_x), len(pi_y), len(v_y)) > 0 else []
+    names = ('{}/{}{}.h5'.format(save_dir, pref, i) for i in range(max(first_version, 0), last_version + 1))
+    sources += [_read(name) for name in names if os.path.exists(name)]
+    if not sources:
+        return [], [], [], 0
+    bx, py, vy = zip(*sources)
+    return np.concatenate(bx), np.concatenate(py), np.concatenate(vy), len(sources)
 
 
 def save_combined(board_x, pi_y, v_y, path='combined.h5'):
