@@ -139,13 +139,14 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         const int rh = r >> 1, ch = c >> 1;
         // directions N,E,SE,S,W,NW = (axis 0,-) (1,+) (2,+) (0,+) (1,-) (2,-); pushed in reverse order (the byte is
         // stored unconditionally and kept only if the landing is legal and unvisited: no branches).
-        // landing of a hop to line position hp: cell x + (hp - pos) * stride; sub-lattice index from its row / column
+        // landing of a hop to line position hp: cell x + (hp - pos) * stride; sub-lattice index from its row / column (a diagonal
+        // hop of 2 h cells moves the index by 4 h + h)
 #define MG_PUSH(HP, POS, STRIDE, IDX) { const int hp = (int)(HP); const int land = x + (hp - (POS)) * (STRIDE); \
                                         stk[sp] = (uint8_t)land; sp += ((hp < 7) & (((visited >> ((IDX) & 15)) & 1u) == 0)) ? 1 : 0; }
-        MG_PUSH(h2 & 0xFF, m, 8, ((r + hp - m) >> 1) * 4 + ((c + hp - m) >> 1))      // NW
+        MG_PUSH(h2 & 0xFF, m, 8, xi + 5 * ((hp - m) >> 1))      // NW
         MG_PUSH(h1 & 0xFF, c, 1, rh * 4 + (hp >> 1))                                 // W
         MG_PUSH(h0 >> 8, r, 7, (hp >> 1) * 4 + ch)                                   // S
-        MG_PUSH(h2 >> 8, m, 8, ((r + hp - m) >> 1) * 4 + ((c + hp - m) >> 1))        // SE
+        MG_PUSH(h2 >> 8, m, 8, xi + 5 * ((hp - m) >> 1))        // SE
         MG_PUSH(h1 >> 8, c, 1, rh * 4 + (hp >> 1))                                   // E
         MG_PUSH(h0 & 0xFF, r, 7, (hp >> 1) * 4 + ch)                                 // N
 #undef MG_PUSH
