@@ -51,3 +51,27 @@ def test_evolve_two_iterations(golden_dir, tmp_path):
     bx, py, vy, used = tr.combine_prev_iters_train_data([], [], [], 2, directory=str(tmp_path / 'data'))
     assert used == 1 and len(bx) == len(np.array(H5File(str(tmp_path / 'data' / 'data-for-iter-1.h5')).get('v_y')))
     assert any('self-play games kept' in l for l in logs) and any('wins' in l for l in logs)
+
+
+def test_gpu_training_step_equals_cpu(golden_dir):
+    """next-2: the optimisation step on the GPU against the same step on the CPU (float32 both): same weights, same batch of 32 ->
+    the same losses and the same updated tensors (BatchNorm moving statistics included) to float32 rounding"""
+    import torch
+    from chinesecheckersagent_amd import train as T
+    net = np.load(golden_dir + '/net.npz')
+    x = torch.from_numpy(net['planes'][:32].astype(np.float32))
+    g = torch.Generator().manual_seed(3)
+    pi = torch.softmax(torch.randn(32, 294, generator=g), dim=1)
+    z = torch.tensor([1.0, -1.0] * 16)
+    out = {}
+    for dev in ('cpu', 'cuda'):
+        t = T.Trainer(device=dev)
+        t.load_weights(golden_dir + '/good_model.h5')
+        losses = [t.step(x.to(dev), pi.to(dev), z.to(dev)) for _ in range(3)]
+        out[dev] = (losses, t.state_as_keras())
+    for a, b in zip(out['cpu'][0], out['cuda'][0]):
+        assert np.allclose(a, b, rtol=2e-5, atol=2e-6), (a, b)
+    for k, v in out['cpu'][1].items():
+        assert np.abs(v - out['cuda'][1][k]).max() < 5e-6 * max(1.0, float(np.abs(v).max())), k
+    # the step moved the weights, and in the direction that lowers the loss on this batch
+    assert out['cuda'][0][2][0] < out['cuda'][0][0][0]
