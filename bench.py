@@ -158,19 +158,21 @@ def cpu_baseline(seconds=8.0, sims=400):
 # ---- timed regions -------------------------------------------------------------------------------------------------
 
 def timed_plies(eng, evaluator, steps, torch):
-    """`steps` plies of the fused path; returns (wall seconds, avg ms of one ply's launches by HIP events recorded on
-    the stream the kernels are launched on)"""
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    """`steps` plies of the fused path in ONE ccsp_play_plies call (the library carries every game through up to
+    ccsp_debug_plies_per_launch plies per launch of fused_plies_kernel); returns (wall seconds, avg ms per ply by HIP events
+    recorded on the stream the kernels are launched on, number of launches)"""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    from chinesecheckersagent_amd import _lib
+    ppl = _lib.lib().ccsp_debug_plies_per_launch(0)
     torch.cuda.synchronize()
     t0 = time.time()
-    for a, b in ev:
-        a.record()
-        eng.play_plies(evaluator, 1)
-        b.record()
+    a.record()
+    eng.play_plies(evaluator, steps)
+    b.record()
     torch.cuda.synchronize()
     wall = time.time() - t0
-    kms = [a.elapsed_time(b) for a, b in ev]
-    return wall, float(np.mean(kms))
+    launches = (steps + ppl - 1) // ppl if ppl > 1 and steps > 1 else 3 * steps
+    return wall, a.elapsed_time(b) / steps, launches
 
 
 def weights_path():
@@ -304,7 +306,7 @@ def main():
     barrier()
     c0 = eng.counters()
     t0 = time.time()
-    wall, kernel_ms = timed_plies(eng, EV, K, torch)
+    wall, kernel_ms, launches = timed_plies(eng, EV, K, torch)
     barrier()
     elapsed = time.time() - t0
     c1 = eng.counters()
@@ -323,7 +325,8 @@ def main():
         alg = alg_bytes_per_expansion(D, Kc)
         own = structure_bytes_per_expansion(D, Kc)
         achieved = exp_per_launch * alg / (kernel_ms * 1e-3) / 1e9
-        roof = {'bound': 'hbm', 'kernel': 'fused_sims_kernel (one ply = begin + sims + end launches)',
+        roof = {'bound': 'hbm', 'kernel': 'fused_plies_kernel (one wave per game: root expansion, %d simulations and the move, ply after ply; '
+                                          '%d launches for the %d timed plies; the per-launch figures below are per PLY = launch / plies)' % (S, launches, K),
                 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
                 'algorithmic_model': 'SURVEY.md 8d: 20DK + 56K + 24D + 3956 bytes per expansion (charges planes, policy row and '
                                      'child positions that the fused kernel of config 2a never materialises)',
@@ -451,7 +454,7 @@ def extras(eng, G, S, torch, _lib, engine):
     e.play_plies(_lib.EVAL_ROLLOUT, 1)
     torch.cuda.synchronize()
     c0 = e.counters()
-    wall, kms = timed_plies(e, _lib.EVAL_ROLLOUT, 2, torch)
+    wall, kms, _ = timed_plies(e, _lib.EVAL_ROLLOUT, 2, torch)
     c1 = e.counters()
     v['2b_rollout'] = {'node_expansions_per_s': (c1['expansions'] - c0['expansions']) / wall, 'ms_per_ply': kms,
                        'workload': '%d games x %d sims, v = random playout <= 64 plies, p = 1/294' % (G, S)}

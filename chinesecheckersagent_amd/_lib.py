@@ -57,6 +57,7 @@ _SIGS = {
     'ccsp_encode': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     'ccsp_greedy_best': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP]),
     'ccsp_debug_movegen_stack_cap': (C.c_int, [C.c_int]),
+    'ccsp_debug_plies_per_launch': (C.c_int, [C.c_int]),
     'ccsp_net_plain_size': (C.c_int, []),
     'ccsp_net_packed_size': (C.c_int, []),
     'ccsp_net_pack': (C.c_int, [_VP, _VP]),

@@ -104,7 +104,6 @@ struct Params {
     unsigned long long log_cap;
     unsigned long long *log_count;
     ccsp_game_result *results;
-    unsigned long long *next_index;
     unsigned long long max_games;
     uint64_t first_game, stride, seed;
     int n_slots, sims, randomised, auto_restart, max_plies;
@@ -653,6 +652,15 @@ __device__ __forceinline__ void slot_start_game(const Params &P, Lds &lds, Slot 
 // move count limit when enforce_move_limit.  `useless` holds num_moves.
 __device__ __forceinline__ void slot_finish(const Params &P, Lds &lds, Slot &sl, int status, Tally &tl);
 
+// auto_restart: slot g plays the game indices g, g + n_slots, g + 2 n_slots, ... below max_games.  No shared counter: which game
+// a slot plays next does not depend on which other slot finished first, so a run is reproducible whatever the number of plies a
+// launch carries (fused_plies_kernel) and however the waves are scheduled.
+__device__ __forceinline__ void slot_restart(const Params &P, Lds &lds, Slot &sl) {
+    const unsigned long long idx = sl.index + (unsigned long long)P.n_slots;
+    if (idx < P.max_games) slot_start_game(P, lds, sl, idx);
+    else sl.status = CCSP_ST_IDLE;
+}
+
 __device__ __forceinline__ void slot_after_move_arena(const Params &P, Lds &lds, Slot &sl, int id, int dest, Tally &tl) {
     const ccsp_sr ns = ccsp_place(sl.st, (int)sl.player, id, dest);
     sl.st = ns;
@@ -702,13 +710,7 @@ __device__ __forceinline__ void slot_finish(const Params &P, Lds &lds, Slot &sl,
         const uint64_t w0 = (uint64_t)(uint32_t)status | ((uint64_t)reward << 8) | ((uint64_t)(sl.ply & 0xFFFF) << 16) | ((uint64_t)sl.n_hist << 32);
         *reinterpret_cast<ulonglong2 *>(P.results + sl.index) = make_ulonglong2(w0, sl.expansions);
     }
-    if (P.auto_restart) {
-        unsigned long long idx = 0;
-        if (lane_id() == 0) idx = atomicAdd(P.next_index, 1ULL);
-        idx = uni64(idx);
-        if (idx < P.max_games) slot_start_game(P, lds, sl, idx);
-        else sl.status = CCSP_ST_IDLE;
-    }
+    if (P.auto_restart) slot_restart(P, lds, sl);
 }
 
 // selfplay.py:38-74 after a ply was played: `moved` = (from, to) by sl.player on sl.st -> updates sl
@@ -765,13 +767,7 @@ __device__ __forceinline__ void slot_after_move(const Params &P, Lds &lds, Slot 
             const uint64_t w0 = (uint64_t)(uint32_t)status | ((uint64_t)reward << 8) | ((uint64_t)(sl.ply & 0xFFFF) << 16) | ((uint64_t)sl.n_hist << 32);
             *reinterpret_cast<ulonglong2 *>(P.results + sl.index) = make_ulonglong2(w0, sl.expansions);
         }
-        if (P.auto_restart) {
-            unsigned long long idx = 0;
-            if (lane_id() == 0) idx = atomicAdd(P.next_index, 1ULL);
-            idx = uni64(idx);
-            if (idx < P.max_games) slot_start_game(P, lds, sl, idx);
-            else sl.status = CCSP_ST_IDLE;
-        }
+        if (P.auto_restart) slot_restart(P, lds, sl);
     }
 }
 
@@ -1065,13 +1061,7 @@ __global__ __launch_bounds__(64) void reset_kernel(Params P) {
 // compact context in registers.  Word 14 of the slot record = "searching" flag between the three.
 
 // (1) opening move (selfplay.py:32-33), or root expansion + Dirichlet noise (selfplay.py:114-124)
-__global__ __launch_bounds__(64) void fused_begin_kernel(Params P, int evaluator) {
-    __shared__ Lds lds;
-    const int g = blockIdx.x;
-    Slot sl = load_slot(P.slots + g);
-    if (sl.status != CCSP_ST_RUNNING) return;
-    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
-    __syncthreads();
+__device__ __forceinline__ void fused_begin_core(const Params &P, Lds &lds, int g, Slot &sl, int evaluator) {   // lds.T is loaded
     uint8_t *pool = P.pool + (uint64_t)g * P.pool_stride;
     Tally tl; tally_zero(tl);
     uint32_t searching = 0;
@@ -1095,15 +1085,20 @@ __global__ __launch_bounds__(64) void fused_begin_kernel(Params P, int evaluator
     tally_flush(P, tl);
 }
 
-// (2) the simulations (MCTS.py:123-125): select -> evaluate -> expand -> backup, `sims` times
-__global__ __launch_bounds__(64, 4) void fused_sims_kernel(Params P, int evaluator) {
+__global__ __launch_bounds__(64) void fused_begin_kernel(Params P, int evaluator) {
     __shared__ Lds lds;
     const int g = blockIdx.x;
+    Slot sl = load_slot(P.slots + g);
+    if (sl.status != CCSP_ST_RUNNING) return;
+    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
+    __syncthreads();
+    fused_begin_core(P, lds, g, sl, evaluator);
+}
+
+// (2) the simulations (MCTS.py:123-125): select -> evaluate -> expand -> backup, `sims` times
+__device__ __forceinline__ void fused_sims_core(const Params &P, Lds &lds, int g, int evaluator) {   // lds.T is loaded
     const int lane = lane_id();
     SlotMem *sm = P.slots + g;
-    if (uni64(sm->w[14]) != 1) return;
-    ccsp_load_lines_to_lds(&lds.T, lane, 64);
-    __syncthreads();
     SimCtx cx;
     {
         const uint64_t w8 = uni64(sm->w[8]), w9 = uni64(sm->w[9]), w10 = uni64(sm->w[10]), w11 = uni64(sm->w[11]);
@@ -1166,14 +1161,17 @@ __global__ __launch_bounds__(64, 4) void fused_sims_kernel(Params P, int evaluat
     }
 }
 
-// (3) pi, sampling, sample-log row, Board.place, end-of-ply rules (MCTS.py:127-153, selfplay.py:38-74)
-__global__ __launch_bounds__(64) void fused_end_kernel(Params P) {
+__global__ __launch_bounds__(64, 4) void fused_sims_kernel(Params P, int evaluator) {
     __shared__ Lds lds;
     const int g = blockIdx.x;
     if (uni64(P.slots[g].w[14]) != 1) return;
-    Slot sl = load_slot(P.slots + g);
-    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);        // (the opening plies of a restarted game generate moves)
+    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
     __syncthreads();
+    fused_sims_core(P, lds, g, evaluator);
+}
+
+// (3) pi, sampling, sample-log row, Board.place, end-of-ply rules (MCTS.py:127-153, selfplay.py:38-74)
+__device__ __forceinline__ void fused_end_core(const Params &P, Lds &lds, int g, Slot &sl) {              // lds.T is loaded
     uint8_t *pool = P.pool + (uint64_t)g * P.pool_stride;
     Tally tl; tally_zero(tl);
     const uint64_t game0 = sl.game;
@@ -1182,6 +1180,37 @@ __global__ __launch_bounds__(64) void fused_end_kernel(Params P) {
     store_slot(P.slots + g, sl);
     if (lane_id() == 0) P.slots[g].w[14] = 0;
     tally_flush(P, tl);
+}
+
+__global__ __launch_bounds__(64) void fused_end_kernel(Params P) {
+    __shared__ Lds lds;
+    const int g = blockIdx.x;
+    if (uni64(P.slots[g].w[14]) != 1) return;
+    Slot sl = load_slot(P.slots + g);
+    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);        // (the opening plies of a restarted game generate moves)
+    __syncthreads();
+    fused_end_core(P, lds, g, sl);
+}
+
+// The same three phases for `n_plies` plies of ONE game in ONE launch: a wave carries its game from ply to ply without waiting for
+// the slowest game of every ply (a ply's launch lasts as long as its slowest search; the average wave is done a quarter earlier).
+__global__ __launch_bounds__(64, 4) void fused_plies_kernel(Params P, int evaluator, int n_plies) {
+    __shared__ Lds lds;
+    const int g = blockIdx.x;
+    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
+    __syncthreads();
+    for (int i = 0; i < n_plies; i++) {
+        Slot sl = load_slot(P.slots + g);
+        if (sl.status != CCSP_ST_RUNNING) return;
+        fused_begin_core(P, lds, g, sl, evaluator);
+        __syncthreads();                                   // this phase's stores before the next one's loads
+        if (uni64(P.slots[g].w[14]) != 1) continue;
+        fused_sims_core(P, lds, g, evaluator);
+        __syncthreads();
+        sl = load_slot(P.slots + g);
+        fused_end_core(P, lds, g, sl);
+        __syncthreads();
+    }
 }
 
 // stepped path, phase 1: root planes out (or nothing for slots in their opening plies)
@@ -1378,7 +1407,7 @@ int ccsp_destroy(ccsp_ctx *ctx) {
     (void)ctx_enter(ctx, nullptr);
     Params &P = ctx->P;
     void *ptrs[] = {P.slots, P.pend, P.pool, P.path, ctx->sqrt_tab, ctx->pow_tab, ctx->rcp_tab, P.counters, P.stepacc, P.visit_hist,
-                    P.log_state, P.log_meta, P.log_pi, P.log_count, P.results, P.next_index};
+                    P.log_state, P.log_meta, P.log_pi, P.log_count, P.results};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete ctx;
     return CCSP_OK;
@@ -1425,7 +1454,6 @@ ccsp_ctx *ccsp_create(const ccsp_config *cfg, int *err) {
     CTXALLOC(&P.stepacc, G * 8 * sizeof(uint32_t));
     CTXALLOC(&P.visit_hist, CCSP_NUM_ACTIONS * sizeof(unsigned long long));
     CTXALLOC(&P.log_count, sizeof(unsigned long long));
-    CTXALLOC(&P.next_index, sizeof(unsigned long long));
     const uint64_t cap = P.log_cap ? P.log_cap : 1;
     CTXALLOC(&P.log_state, cap * sizeof(ccsp_state));
     CTXALLOC(&P.log_meta, cap * sizeof(ccsp_sample_meta));
@@ -1461,9 +1489,6 @@ int ccsp_reset(ccsp_ctx *ctx, void *stream) {
     CCSP_HIPCHK(hipMemsetAsync(P.visit_hist, 0, CCSP_NUM_ACTIONS * sizeof(unsigned long long), s));
     CCSP_HIPCHK(hipMemsetAsync(P.log_count, 0, sizeof(unsigned long long), s));
     CCSP_HIPCHK(hipMemsetAsync(P.results, 0xFF, P.max_games * sizeof(ccsp_game_result), s));
-    unsigned long long first_free = (unsigned long long)P.n_slots < P.max_games ? (unsigned long long)P.n_slots : P.max_games;
-    CCSP_HIPCHK(hipMemcpyAsync(P.next_index, &first_free, sizeof first_free, hipMemcpyHostToDevice, s));
-    CCSP_HIPCHK(hipStreamSynchronize(s));              // first_free is a stack variable
     hipLaunchKernelGGL(reset_kernel, dim3(P.n_slots), dim3(64), 0, s, P);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 0;
@@ -1499,12 +1524,24 @@ int ccsp_set_positions(ccsp_ctx *ctx, const ccsp_state *states, const uint8_t *p
     return CCSP_OK;
 }
 
+static int g_plies_per_launch = 64;
+int ccsp_debug_plies_per_launch(int n) { const int was = g_plies_per_launch; if (n >= 1) g_plies_per_launch = n; return was; }
+
 int ccsp_play_plies(ccsp_ctx *ctx, int evaluator, int n_plies, void *stream) {
     if (!ctx || n_plies < 0 || evaluator < 0 || evaluator > CCSP_EVAL_ROLLOUT) return CCSP_EINVAL;
     if (n_plies == 0) return CCSP_OK;
     { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
     if (ctx->P.gen) {                                       // greedy data generator: nothing to search
         hipLaunchKernelGGL(greedy_plies_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, n_plies);
+        CCSP_HIPCHK(hipGetLastError());
+        return CCSP_OK;
+    }
+    if (g_plies_per_launch > 1 && n_plies > 1) {           // a wave carries its game through several plies per launch
+        for (int done = 0; done < n_plies; done += g_plies_per_launch) {
+            const int n = n_plies - done < g_plies_per_launch ? n_plies - done : g_plies_per_launch;
+            hipLaunchKernelGGL(fused_plies_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, evaluator, n);
+        }
+        ctx->opening_plies = -1;
         CCSP_HIPCHK(hipGetLastError());
         return CCSP_OK;
     }

@@ -121,7 +121,7 @@ typedef struct ccsp_config {
     int32_t  n_slots;         /* concurrent games on this GPU (4096 in BASELINE.json) */
     int32_t  sims;            /* simulations per move, MCTS_SIMULATIONS (config.py:35; MCTS.py:41) */
     int32_t  randomised;      /* Board(randomised=True) starts (board.py:61-85) */
-    int32_t  auto_restart;    /* 1: a finished slot starts the next game id by itself */
+    int32_t  auto_restart;    /* 1: a finished slot starts its next game by itself: slot g plays game indices g, g + n_slots, ... */
     uint64_t seed;
     uint64_t first_game;      /* global id of this context's first game */
     uint64_t game_stride;     /* id step between consecutive games of this context (= world size) */
@@ -207,6 +207,10 @@ int ccsp_set_positions(ccsp_ctx *ctx, const ccsp_state *states, const uint8_t *p
  * (107-133) = root expansion + Dirichlet noise + `sims` x {moveToLeaf, expandAndBackUp}
  * (MCTS.py:49-118) + pi + action sampling (MCTS.py:121-153) + the end-of-ply rules. */
 int ccsp_play_plies(ccsp_ctx *ctx, int evaluator, int n_plies, void *stream);
+/* Plies one launch of ccsp_play_plies carries each game through (default 64: one wave per game runs root expansion, simulations and
+ * move for ply after ply without waiting for the slowest search of every ply; 1 = three launches per ply).  Results do not depend on
+ * it.  Returns the previous value; n < 1 only reads it. */
+int ccsp_debug_plies_per_launch(int n);
 
 /* Stepped path (external evaluator, e.g. the policy/value net): one ply =
  *   ccsp_ply_begin            root planes out                       (selfplay.py:114-117, utils.py:101)

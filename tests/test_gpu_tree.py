@@ -218,6 +218,39 @@ def test_sharding_independence(eng):
     assert rows == got and len(rows) == 8 * 18
 
 
+def test_plies_per_launch_changes_nothing(eng):
+    """one launch per phase of a ply (begin / simulations / end kernels) == one launch carrying every game through many plies
+    (fused_plies_kernel, the default): same counters, same game results, same sample log row for row, same visit histogram,
+    restarts included (a slot's next game index is slot + k * n_slots: no dependence on which slot finishes first)"""
+    from chinesecheckersagent_amd import _lib
+    L = _lib.lib()
+    was = L.ccsp_debug_plies_per_launch(0)
+    assert was > 1, 'the multi-ply kernel is the default path'
+    runs = []
+    try:
+        for ppl in (1, 5, was):
+            L.ccsp_debug_plies_per_launch(ppl)
+            e = eng.SelfPlayEngine(n_slots=37, sims=12, seed=4242, first_game=3, game_stride=2, max_games=37 * 3, log_capacity=37 * 1200,
+                                   auto_restart=True)
+            e.play_plies(_lib.EVAL_FORWARD, 130)
+            e.play_plies(_lib.EVAL_FORWARD, 1)              # a single ply goes through the three-kernel path whatever the setting
+            e.play_plies(_lib.EVAL_FORWARD, 70)
+            c = e.counters()
+            st, meta, pi = e.log()
+            order = np.lexsort((meta['ply'], meta['game']))
+            res = e.results()
+            sl = e.slots()
+            runs.append((c, st[order].tobytes(), meta[order].tobytes(), pi[order].tobytes(), res.tobytes(), e.visit_histogram().tobytes(),
+                         sl['game'].tobytes(), sl['ply'].tobytes(), [e.tree_digest(g) for g in range(37)]))
+            e.close()
+    finally:
+        L.ccsp_debug_plies_per_launch(was)
+    c = runs[0][0]
+    assert c['games_won'] + c['games_discarded'] > 37 and c['errors'] == 0, 'the run must include restarts'
+    for r in runs[1:]:
+        assert r == runs[0]
+
+
 def test_rollout_evaluator_matches_cpu_restatement(eng):
     """config 2b (random-playout value) has no reference counterpart (the reference has no
     rollouts); its definition lives in DESIGN.md and is restated on the CPU in oracle/ccsp_oracle.c

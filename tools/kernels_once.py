@@ -1,6 +1,6 @@
 """Development aid for the counter passes (tools/pmc_round.sh): a few launches of every kernel of the library on the
 benchmark's shapes -- move generation / step / encode / greedy on 2^22 positions of the SURVEY 8d distribution, the
-evaluator kernel on 2048 positions, four plies of config 2a (fused path), one ply of config 3 (stepped path)."""
+evaluator kernel on 2048 positions, three launches of four plies of config 2a (fused path), one ply of config 3 (stepped path)."""
 import sys
 sys.path.insert(0, '.')
 import torch
@@ -39,7 +39,9 @@ if what in ('all', 'net'):
     torch.cuda.synchronize()
 if what in ('all', 'fused'):
     e = engine.SelfPlayEngine(n_slots=4096, sims=400, seed=bench.SEED, max_games=4096 * 8, log_capacity=4096 * 16, auto_restart=True)
-    e.play_plies(_lib.EVAL_UNIFORM, 10)
+    e.play_plies(_lib.EVAL_UNIFORM, 6)          # the opening plies: a launch of its own (dropped by pmc_aggregate.py as the cold one)
+    for _ in range(3):
+        e.play_plies(_lib.EVAL_UNIFORM, 4)      # fused_plies_kernel, four searched plies per launch
     torch.cuda.synchronize()
     e.close()
 if what == 'stepped':            # hipGraph replays: NOT under --pmc (the counter passes never finished with it)
