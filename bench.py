@@ -321,23 +321,25 @@ def main():
     if rank == 0:
         D = tot['sum_depth'] / max(tot['sims'], 1)
         Kc = tot['sum_children'] / max(tot['expansions'], 1)
-        exp_per_launch = tot['expansions'] / K / world          # per GPU and ply
+        exp_per_ply = tot['expansions'] / K / world             # per GPU
+        ppl = K / launches                                      # plies one launch of fused_plies_kernel carried every game through
+        exp_per_launch, launch_ms = exp_per_ply * ppl, kernel_ms * ppl
         alg = alg_bytes_per_expansion(D, Kc)
         own = structure_bytes_per_expansion(D, Kc)
-        achieved = exp_per_launch * alg / (kernel_ms * 1e-3) / 1e9
-        roof = {'bound': 'hbm', 'kernel': 'fused_plies_kernel (one wave per game: root expansion, %d simulations and the move, ply after ply; '
-                                          '%d launches for the %d timed plies; the per-launch figures below are per PLY = launch / plies)' % (S, launches, K),
+        achieved = exp_per_launch * alg / (launch_ms * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'kernel': 'fused_plies_kernel (one wave per game: root expansion, %d simulations and the move, ply after ply)' % S,
                 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
                 'algorithmic_model': 'SURVEY.md 8d: 20DK + 56K + 24D + 3956 bytes per expansion (charges planes, policy row and '
                                      'child positions that the fused kernel of config 2a never materialises)',
-                'bytes_per_expansion': alg, 'expansions_per_launch': exp_per_launch, 'avg_launch_ms': kernel_ms,
+                'bytes_per_expansion': alg, 'expansions_per_launch': exp_per_launch, 'avg_launch_ms': launch_ms,
+                'launches': launches, 'plies_per_launch': ppl, 'ms_per_ply': kernel_ms,
                 'kernel_structure_bytes_per_expansion': own,
-                'hbm_frac_kernel_structures': exp_per_launch * own / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                'hbm_frac_kernel_structures': exp_per_ply * own / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         try:                                 # PMC figures cannot be taken inside this process: static, from the committed passes
-            prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))['fused_sims_kernel']
+            prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))['fused_plies_kernel']
             if G == 4096 and S == 400:
-                traffic = 2.0 * prof['fetch_size_kb'] * 1024.0 + prof['write_size_kb'] * 1024.0
-                roof['traffic'] = traffic
+                traffic = 2.0 * prof['fetch_size_kb'] * 1024.0 + prof['write_size_kb'] * 1024.0      # per ply
+                roof['traffic'] = traffic * ppl                                                      # per launch, like `achieved`
                 roof['traffic_source'] = 'static: ' + prof['source']
                 roof['hbm_frac_counters'] = traffic / (prof['launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS
                 if 'insts_valu' in prof:

@@ -21,7 +21,16 @@ for step in "$@"; do
     tests_all) run tests 900 python3 -m pytest tests -m gpu -q ;;
     bench) run bench 600 python3 bench.py; grep '^{' gpurun_out/${tag}_bench.log > gpurun_out/${tag}_bench.json ;;
     stats) rm -rf /tmp/st_$tag; run stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$tag -- python3 bench.py --steps 32 --cpu-seconds 1 --net-warmup-plies 8 --net-plies 4
-           f=$(find /tmp/st_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${tag}_bench_kernel_stats.csv ;;
+           f=$(find /tmp/st_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${tag}_bench_kernel_stats.csv
+           f=$(find /tmp/st_$tag -name "*kernel_trace.csv" | head -1)      # every launch of the multi-ply kernel with its own duration
+           [ -n "$f" ] && python3 - "$f" > gpurun_out/${tag}_fused_plies_launches.csv <<'PY'
+import csv, sys
+print('kernel,start_ns,duration_ms')
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'fused_plies_kernel' in r['Kernel_Name']:
+        print('fused_plies_kernel,%s,%.3f' % (r['Start_Timestamp'], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6))
+PY
+           ;;
     pmc*) w=${step#pmc}; w=${w#:}; run pmc 1100 bash tools/pmc_round.sh $tag ${w:-all} ;;
     netexp*) f=${step#netexp}; f=${f#:}; run netexp_$(echo "$f" | tr -c 'A-Za-z0-9\n' '_') 300 python3 tools/bench_net.py ${f//,/ } ;;
     stamps_net*) f=${step#stamps_net}; f=${f#:}; run stamps_net_$(echo "$f" | tr -c 'A-Za-z0-9\n' '_') 300 python3 tools/stamps_net.py ${f//,/ } ;;
