@@ -9,7 +9,8 @@ with the model and losses of model.py:58-87 / loss.py:3-4 on PyTorch(-ROCm):
     BatchNormalization(momentum=0.99, epsilon=1e-3) in training mode (Keras defaults, model.py:63)
 
 PARITY UNPINNED: Keras/TensorFlow are not installed and the reference holds no training vectors, so this
-follows the documented Keras 2.1.6 semantics without an executable oracle.  Multi-GPU: one
+follows the documented Keras 2.1.6 semantics; its step is checked against a hand-derived NumPy float64 restatement of those
+semantics (oracle/train_oracle.py, tests/test_train.py), not against Keras itself.  Multi-GPU: one
 process per GPU, DistributedDataParallel (RCCL) averages the 999,408-byte gradient each step.
 Weights are read from and written to the reference's own `versionNNNN-weights.h5` layout (h5lite).
 """

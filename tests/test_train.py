@@ -219,3 +219,39 @@ def test_against_keras_step_when_present(golden_dir):
         assert key in st, name
         worst = max(worst, float(np.abs(st[key] - k[name]).max()))
     assert worst < 1e-5, worst
+
+
+def test_step_equals_hand_derived_numpy_restatement(net, golden_dir):
+    """next-2: two optimisation steps of the product's trainer (PyTorch autograd, run in float64 here) against oracle/train_oracle.py
+    -- the same step derived by hand in NumPy float64 (training-mode BatchNorm, the three loss terms, every gradient, Keras' Nesterov
+    update, the moving statistics): losses, all 186 tensors after each step"""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import train_oracle
+    from chinesecheckersagent_amd import train as T
+    t = T.Trainer(device='cpu')
+    t.load_weights(golden_dir + '/good_model.h5')
+    t.net.double()
+    rs = np.random.RandomState(5)
+    x = net['planes'][:24].reshape(-1, 7, 7, 7).astype(np.float64)
+    pi = rs.dirichlet(np.ones(294) * 0.1, size=24)
+    z = rs.choice([-1.0, 1.0], size=24)
+    w = {k: v.astype(np.float64) for k, v in t.state_as_keras().items()}
+    assert len(w) == 186
+    vel = {}
+    for it in range(2):
+        got = t.step(torch.from_numpy(x), torch.from_numpy(pi), torch.from_numpy(z))
+        want, w, vel, grads = train_oracle.step(w, vel, x, pi, z)
+        assert np.allclose(got, want, rtol=1e-10, atol=1e-12), (it, got, want)
+        st = t.state_as_keras()
+        assert set(st) == set(w)
+        for k in sorted(w):
+            scale = max(1e-12, float(np.abs(w[k]).max()))
+            assert np.abs(st[k] - w[k]).max() < 1e-10 * max(1.0, scale), (it, k, float(np.abs(st[k] - w[k]).max()))
+    # the step is not a no-op: gradients and updates are far above the comparison's resolution
+    assert max(float(np.abs(g).max()) for g in grads.values()) > 1e-3
+    t0 = T.Trainer(device='cpu'); t0.load_weights(golden_dir + '/good_model.h5')
+    w0 = t0.state_as_keras()
+    moved = [float(np.abs(w[k] - w0[k]).max()) for k in sorted(w)]
+    # (the 30 convolution biases sit in front of a BatchNormalization: their gradient is zero)
+    assert sum(m > 1e-9 for m in moved) == 186 - 30 and max(moved) > 1e-6
