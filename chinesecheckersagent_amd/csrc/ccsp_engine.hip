@@ -1125,8 +1125,12 @@ __device__ __forceinline__ void fused_sims_core(const Params &P, Lds &lds, int g
 #ifdef CCSP_STAMPS
         STAMP(t0);
 #endif
+        // issue priority: a wave in its expansion (a long dependent chain of LDS look-ups with few instructions) goes before the
+        // waves that are selecting (wide, independent arithmetic between memory round trips): +6 % on config 2a, measured
+        __builtin_amdgcn_s_setprio(0);
         const Leaf lf = use_rcp ? wave_select<true>(sqrt_tab, lds.rcp, cx, pool, path, sim, mypath, myW, myN, select_edges)
                                 : wave_select<false>(sqrt_tab, nullptr, cx, pool, path, sim, mypath, myW, myN, select_edges);
+        __builtin_amdgcn_s_setprio(2);
 #ifdef CCSP_STAMPS
         STAMP(t1); t_sel += t1 - t0; t0 = t1;
 #endif
@@ -1248,6 +1252,7 @@ __global__ __launch_bounds__(64) void root_expand_kernel(Params P, const double 
 // stepped path, phase 3: selection; leaf planes out; hand-off record for expand_backup
 __global__ __launch_bounds__(64) void select_kernel(Params P, float *planes) {
     __shared__ Lds lds;
+    __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch (stepped path): the short tree kernels go first, the next evaluator launch waits for them
     const int g = blockIdx.x;
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING || no_search(P, sl) || sl.sim >= (uint32_t)P.sims) {
@@ -1275,6 +1280,7 @@ __global__ __launch_bounds__(64) void select_kernel(Params P, float *planes) {
 // stepped path, phase 4: expansion with (p, v) + backup
 __global__ __launch_bounds__(64) void expand_backup_kernel(Params P, const double *p, const float *v) {
     __shared__ Lds lds;
+    __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch (stepped path): the short tree kernels go first, the next evaluator launch waits for them
     const int g = blockIdx.x;
     Pending pd;
     {
