@@ -58,6 +58,14 @@ def structure_bytes_per_expansion(D, K):
 
 # ---- multi-GPU launcher ---------------------------------------------------------------------------------------------
 
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a torchrun around it: start the N rank processes from THIS process, which
     never touches the GPU (no torch.cuda / libccsp call before or after), wait for them, pass rank 0's JSON line
@@ -270,8 +278,15 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     coll_dev = 'cuda'
-    if world > 1:
+    # CCSP_BENCH_FORCE_DIST=1 (test hook for 1-GPU boxes): a world of ONE rank still goes through RCCL -- process group on the
+    # device, the MAX / SUM all-reduces and the all-gather of the summary -- so that the collective code the N-GPU runs use has
+    # executed on the hardware at least once
+    if world > 1 or os.environ.get('CCSP_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
+            os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1'); os.environ.setdefault('LOCAL_RANK', '0')
         if one_dev:
             dist.init_process_group('gloo')
             coll_dev = 'cpu'

@@ -332,3 +332,26 @@ def test_bench_launcher_world2_on_one_device(tmp_path):
         assert 'skipped' not in c3 and c3['errors'] == 0 and c3['node_expansions_per_s'] > 0 and c3['roofline']['bound'] == 'mfma'
     assert sum(two['config3']['per_rank_expansions']) == one['config3']['per_rank_expansions'][0]
     assert 'variants' in one and 'variants' not in two
+
+
+def test_bench_summary_collectives_through_rccl_world1():
+    """§8e: the summary collectives of the N-GPU bench (process group on the device, MAX / SUM all-reduce, all-gather, barrier)
+    through RCCL itself -- a world of one rank, which is all a 1-GPU box allows (CCSP_BENCH_FORCE_DIST=1); the result must equal
+    the plain 1-GPU run"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    common = ['--games', '64', '--sims', '24', '--steps', '3', '--warmup', '1', '--net-warmup-plies', '7', '--net-plies', '2', '--cpu-seconds', '0.3']
+
+    def run(**envx):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + common, env=dict(env, **envx), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    a, b = run(CCSP_BENCH_FORCE_DIST='1'), run()
+    assert a['n_gpus'] == b['n_gpus'] == 1 and a['errors'] == 0
+    assert a['per_rank_expansions'] == b['per_rank_expansions'] and a['visit_histogram_sum'] == b['visit_histogram_sum']
+    assert a['config3']['per_rank_expansions'] == b['config3']['per_rank_expansions'] and 'skipped' not in a['config3']

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_selfplay_train_arena_loop(golden_dir, tmp_path):
@@ -75,3 +76,41 @@ def test_gpu_training_step_equals_cpu(golden_dir):
         assert np.abs(v - out['cuda'][1][k]).max() < 5e-6 * max(1.0, float(np.abs(v).max())), k
     # the step moved the weights, and in the direction that lowers the loss on this batch
     assert out['cuda'][0][2][0] < out['cuda'][0][0][0]
+
+
+def test_ddp_training_step_through_rccl_world1(golden_dir, tmp_path):
+    """next-2 on N GPUs is DistributedDataParallel over RCCL; a 1-GPU box allows a world of one rank: process group on the device,
+    gradient all-reduce through RCCL, and the result equals the plain single-process step (the mean over one rank)"""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent('''
+        import os, sys, numpy as np, torch
+        import torch.distributed as dist
+        sys.path.insert(0, %r)
+        from chinesecheckersagent_amd import train as T
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[1], RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+        net = np.load(%r)
+        x = torch.from_numpy(net['planes'][:32].astype(np.float32)).cuda()
+        g = torch.Generator().manual_seed(3)
+        pi = torch.softmax(torch.randn(32, 294, generator=g), dim=1).cuda()
+        z = torch.tensor([1.0, -1.0] * 16).cuda()
+        out = []
+        for ddp in (True, False):
+            t = T.Trainer(device='cuda:0', ddp=ddp)
+            t.load_weights(%r)
+            losses = [t.step(x, pi, z) for _ in range(2)]
+            out.append((losses, t.state_as_keras()))
+        dist.barrier(); dist.destroy_process_group()
+        assert np.allclose(out[0][0], out[1][0], rtol=1e-6, atol=1e-7), (out[0][0], out[1][0])
+        for k, v in out[0][1].items():
+            assert np.abs(v - out[1][1][k]).max() <= 1e-6 * max(1.0, float(np.abs(v).max())), k
+        print('ddp over rccl ok')
+    ''') % (ROOT, golden_dir + '/net.npz', golden_dir + '/good_model.h5')
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, '-c', code, str(port)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ddp over rccl ok' in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
