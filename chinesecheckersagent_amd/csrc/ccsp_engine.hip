@@ -1057,8 +1057,9 @@ __global__ __launch_bounds__(64) void reset_kernel(Params P) {
     if (lane_id() == 0) { P.pend[g].kind = 0; P.slots[g].w[14] = 0; P.slots[g].w[15] = 0; }
 }
 
-// ---- fused path (built-in evaluator): one ply = three launches, so that the simulation loop carries only a
-// compact context in registers.  Word 14 of the slot record = "searching" flag between the three.
+// ---- fused path (built-in evaluator): a ply = three phases -- begin, simulations, end -- which hand the game over through its slot
+// record, so that the simulation loop carries only a compact context in registers (word 14 of the record = "searching" flag between
+// the phases).  fused_plies_kernel runs them ply after ply in one launch; the three kernels launch one phase each.
 
 // (1) opening move (selfplay.py:32-33), or root expansion + Dirichlet noise (selfplay.py:114-124)
 __device__ __forceinline__ void fused_begin_core(const Params &P, Lds &lds, int g, Slot &sl, int evaluator) {   // lds.T is loaded
