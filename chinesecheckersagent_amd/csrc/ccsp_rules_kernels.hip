@@ -79,27 +79,44 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     }
     __syncthreads();
 
+    const int ntasks = here * 6;
+    // ---- walks: lane = task, three rounds.  Direction order N,E,SE,S,W,NW (board.py:149-155), read off the three line patterns
+    // through the origin (bits beyond a line's end are preset; the byte is stored unconditionally, kept only if legal).  Done here,
+    // with every lane busy, instead of inside the search loop, where the lanes reach their origins at different iterations and the
+    // whole wave would step through these ~90 instructions every time one of them does.
+    for (int t = lane; t < ntasks; t += 64) {
+        const int s = (int)(__umul24((unsigned)t, 171u) >> 10), c = t - 6 * s;      // t / 6, exact for t < 515
+        const int x = L.lists[s][c][MG_SLOT - 1];
+        const int r = (int)(__umul24((unsigned)x, 37u) >> 8), col = x - 7 * r, m = r < col ? r : col;
+        const uint8_t *pat = L.lines[s];
+        const uint32_t p0 = pat[col], p1 = pat[7 + r], p2 = pat[20 + r - col];
+        int k = 0;
+#define MG_WALK(P, POS, D, STEP) { const int np = (POS) + (D); const bool ok = (np >= 0) & (np <= 6) & ((((P) >> (np & 7)) & 1u) == 0); \
+                                   L.lists[s][c][k] = (uint8_t)(x + (STEP)); k += ok ? 1 : 0; }
+        MG_WALK(p0, r, -1, -7) MG_WALK(p1, col, 1, 1) MG_WALK(p2, m, 1, 8) MG_WALK(p0, r, 1, 7) MG_WALK(p1, col, -1, -1) MG_WALK(p2, m, -1, -8)
+#undef MG_WALK
+        L.cnt[s][c] = (uint8_t)k;
+    }
+    __syncthreads();
+
     // ---- task loop: lane = worker ---------------------------------------------------------------------------
     // The ordered hop search (board.py:166-211) with an explicit stack: popping a cell that is still unvisited
     // visits it (= the recursive call), looks up the mirror hop in all six directions (three line patterns, two
     // senses each: one 16-bit read per pattern) and pushes the legal unvisited landings, last direction first, so
     // that the first one is on top; a popped cell that was reached through another branch in the meantime is dropped
     // (= the `not in hops` test of the caller's loop).  One iteration per visited cell instead of one per hop test.
-    const int ntasks = here * 6;
     int task = lane;                                    // current task (position-major: task = 6 * s + c)
     int next = 64;                                      // next unassigned task of the chunk (wave-uniform)
     int st_s = 0, st_c = 0, origin = 0, cnt_n = 0, sp = 0, orow = 0, oc = 0;
     uint32_t visited = 0;                               // sub-lattice cells seen: bit (row / 2) * 4 + column / 2
-    uint64_t mask = 0;                                  // destination cells (walks + hop cells), for dest_mask
     bool active = false;
-    const bool want_mask = dest_mask != nullptr;
 
-    // a task starts with its origin on the stack: the origin's visit (always the first) also lists the walks
+    // a task starts with its origin on the stack, its list holding the walks
     auto start_task = [&](int t, uint8_t *stk) {
         st_s = (int)(__umul24((unsigned)t, 171u) >> 10);                   // t / 6, exact for t < 515 (tasks: < 192)
         st_c = t - 6 * st_s;
         origin = L.lists[st_s][st_c][MG_SLOT - 1];
-        cnt_n = 0; mask = 0; visited = 0;
+        cnt_n = L.cnt[st_s][st_c]; visited = 0;
         orow = (int)(__umul24((unsigned)origin, 37u) >> 8); oc = origin - 7 * orow;
         stk[0] = (uint8_t)origin; sp = 1;
     };
@@ -119,19 +136,8 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         if (c == oc) p0 &= ~(1u << orow);
         if (r == orow) p1 &= ~(1u << oc);
         if (r - c == orow - oc) p2 &= ~(1u << om);
-        if (x == origin) {
-            // the task's first visit: the walks, direction order N,E,SE,S,W,NW (board.py:149-155), read off the same three
-            // patterns (bits beyond a line's end are preset; the byte is stored unconditionally, kept only if legal)
-#define MG_WALK(P, POS, D, STEP) { const int np = (POS) + (D); const bool ok = (np >= 0) & (np <= 6) & ((((P) >> (np & 7)) & 1u) == 0); \
-                                   const int cell = x + (STEP); L.lists[st_s][st_c][cnt_n] = (uint8_t)cell; cnt_n += ok ? 1 : 0; \
-                                   if (want_mask) mask |= ok ? 1ULL << (cell & 63) : 0ULL; }
-            MG_WALK(p0, r, -1, -7) MG_WALK(p1, c, 1, 1) MG_WALK(p2, m, 1, 8) MG_WALK(p0, r, 1, 7) MG_WALK(p1, c, -1, -1) MG_WALK(p2, m, -1, -8)
-#undef MG_WALK
-        } else {
-            L.lists[st_s][st_c][cnt_n] = (uint8_t)x;                    // a hop landing (the origin itself is not a move)
-            cnt_n += 1;
-            if (want_mask) mask |= 1ULL << x;
-        }
+        L.lists[st_s][st_c][cnt_n] = (uint8_t)x;                        // a hop landing (the byte stored for the origin itself, which is
+        cnt_n += x != origin ? 1 : 0;                                   // not a move, is overwritten by the next landing)
         // both senses of a line in one 16-bit read: low byte = sense -, high byte = sense +
         const uint32_t h0 = *reinterpret_cast<const uint16_t *>(&T.hop[p0][r][0]);
         const uint32_t h1 = *reinterpret_cast<const uint16_t *>(&T.hop[p1][c][0]);
@@ -152,10 +158,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
 #undef MG_PUSH
         return true;
     };
-    auto finish_task = [&]() {
-        L.cnt[st_s][st_c] = (uint8_t)cnt_n;
-        if (want_mask) dest_mask[(base + st_s) * 6 + st_c] = mask;
-    };
+    auto finish_task = [&]() { L.cnt[st_s][st_c] = (uint8_t)cnt_n; };
     uint8_t *stk = L.stack[lane];
     if (task < ntasks) { start_task(task, stk); active = true; }
 
@@ -195,6 +198,19 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     }
     __syncthreads();
 
+    // ---- destination masks (optional output): lane = task, the cells of its finished list.  (Tried instead: the walk cells
+    // stored here in the walk phase and the hop cells ORed in by an atomic when a task ends -- the extra instructions in the search
+    // loop cost more; LDS atomics from the write-out lanes -- one word per checker serialises them.) ---------------------------
+    if (dest_mask != nullptr) {
+        for (int t = lane; t < ntasks; t += 64) {
+            const int s = (int)(__umul24((unsigned)t, 171u) >> 10), c = t - 6 * s;
+            const int k = L.cnt[s][c];
+            uint64_t m = 0;
+            for (int i = 0; i < k; i++) m |= 1ULL << L.lists[s][c][i];
+            dest_mask[base * 6 + t] = m;
+        }
+        __syncthreads();                                // the counts are rewritten below
+    }
     // ---- write out in the reference's move order: half a wave per position, lane = move slot ------------------
     if (lane < here) {                                  // prefix sums of the six per-checker counts, packed one byte each
         uint64_t pre = 0; int acc = 0;
