@@ -41,6 +41,9 @@ constexpr int LDX = CCSP_NET_LDX;        // row stride of the 64-channel buffer 
 constexpr int LDY = CCSP_NET_LDY;        // row stride of the 32-channel buffers
 constexpr int LDI = 12;                  // input planes: 7 channels + zeros; 12 spreads eight consecutive cells over all banks
 constexpr int NPOL = 294, NPOL_PAD = 304;
+#ifndef CCSP_NET_PDG
+#define CCSP_NET_PDG 1                   // policy dense: groups of four k the weight loads run ahead
+#endif
 #ifndef CCSP_NET_SHAPE
 #define CCSP_NET_SHAPE 8                 // default workgroup shape of ccsp_net_forward (see Cfg)
 #endif
@@ -65,7 +68,7 @@ constexpr Layout make_layout() {
         L.l3_w[i] = take(4 * 2 * 256); L.l3_b[i] = take(64);
     }
     L.pc_w = take(1 * 4 * 256); L.pc_b = take(16);
-    L.pf_w = take(19 * 25 * 256); L.pf_b = take(NPOL_PAD);
+    L.pf_w = take(5 * 100 * 256); L.pf_b = take(NPOL_PAD);      // [tile of 64 columns][group of 4 k][lane = column][k]
     L.vc_w = take(64); L.vc_b = take(1);
     L.f1_w = take(25 * 32); L.f1_b = take(32);
     L.f2_w = take(32); L.f2_b = take(1);
@@ -517,56 +520,80 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     __syncthreads();
     NET_STAMP(29);
 
-    // ---- policy dense 400 -> 294: 19 column tiles, the positions are the MFMA's second operand ----------------------
-    // A wave owns column tiles wave, wave + NW, wave + 2 NW ... and runs them TOGETHER: one activation fragment per
-    // k-block feeds NTW independent accumulators, and the weights (470 KB, streamed from L2 by every workgroup) come through
-    // scalar-addressed buffer loads two k-blocks ahead.  Transposed like the other layers (tile_out): a lane holds four
-    // consecutive logits of ONE position, and since a position's column of the product depends on that position's
-    // activations only, the lanes of the unused columns (positions >= NB of the 16) simply re-read a real position --
-    // no zero rows, no masks in the loop.  A tile past the 19th (a wave's last share may be empty) is skipped by one scalar
-    // branch per k-block.
+    // ---- policy dense 400 -> 294 on v_mfma_f32_4x4x1_16B_f32: sixteen independent 4 x 4 outer products per instruction (64 FLOP per
+    // cycle like the other fp32 MFMAs).  A 16 x 16 tile would hold the workgroup's 8 (or 4) positions in 16 rows -- half (three
+    // quarters) of every instruction wasted.  Here block b of an instruction is (4 positions) x (output columns 4b .. 4b+3) for ONE k:
+    // lane l supplies the activation of position l & 3 and the weight of column 64 T + l (tools/probe/mfma_4x4_probe.hip: D[reg r] of
+    // lane l = A[lane 4 (l >> 2) + r] * B[lane l]) and ends up with its column's logits of four positions; eight positions = two
+    // instructions on the same weight register.  No row of any tile is empty.
+    // Work split: wave = (k-quarter kq, tile half th): 25 groups of four k for the column tiles of its half (3 + 2 of the five 64-wide
+    // tiles; both waves of a SIMD together 5), every weight crosses L2 -> registers exactly once per workgroup (16 bytes per lane and
+    // group, scalar-addressed, two groups ahead).  The four k-quarters' partial sums meet in LDS (the trunk buffer is dead by now) and
+    // every logit is ((q0 + q1) + q2) + q3 + bias -- the same chains for every position, whatever its slot or the workgroup shape.
+    float *part = S.x;                                   // [4][NB][320] partial sums
+    static_assert(4 * NB * 320 <= MT * 16 * LDX, "the dense layer's partial sums alias the trunk buffer");
     {
-        constexpr int KBP = 25, PD = 3;                              // ring of PD slots: PD - 1 k-blocks in flight
-        int woff[NTW];
-        bool valid[NTW];
+        constexpr int GPQ = 25, NHALF = NW / 4, TPW = (5 + NHALF - 1) / NHALF, PG = NB / 4, PDG = CCSP_NET_PDG;
+        const int kq = wave & 3, th = wave >> 2;
+        int woff[TPW];
+        bool valid[TPW];
 #pragma unroll
-        for (int i = 0; i < NTW; i++) {
-            const int nt = wave + NW * i;
-            valid[i] = nt < 19;
-            woff[i] = LAY.pf_w + (valid[i] ? nt : 0) * KBP * 256;
+        for (int t = 0; t < TPW; t++) {
+            const int T = th * TPW + t;
+            valid[t] = T < 5;
+            woff[t] = LAY.pf_w + ((valid[t] ? T : 0) * 100 + kq * GPQ) * 256;
         }
-        f32x4 acc[NTW], bq[PD][NTW];
+        f32x4 acc[TPW][PG], bq[PDG + 1][TPW];
 #pragma unroll
-        for (int i = 0; i < NTW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TPW; t++)
 #pragma unroll
-        for (int d = 0; d + 1 < PD; d++)
+            for (int g = 0; g < PG; g++) acc[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < NTW; i++) bq[d][i] = wb.load(woff[i] + d * 256);
-        const float *arow = &pc[(l15 & (NB - 1)) * 400 + 4 * q];
-        f32x4 a[2];
-        a[0] = *reinterpret_cast<const f32x4 *>(arow);
+        for (int d = 0; d < PDG; d++)
 #pragma unroll
-        for (int kb = 0; kb < KBP; kb++) {
-            if (kb + 1 < KBP) a[(kb + 1) & 1] = *reinterpret_cast<const f32x4 *>(arow + (kb + 1) * 16);
-            if (kb + PD - 1 < KBP) {
+            for (int t = 0; t < TPW; t++) bq[d][t] = wb.load(woff[t] + d * 256);
+        const float *arow = &pc[(lane & 3) * 400 + kq * GPQ * 4];
+        f32x4 a[2][PG];
 #pragma unroll
-                for (int i = 0; i < NTW; i++) bq[(kb + PD - 1) % PD][i] = wb.load(woff[i] + (kb + PD - 1) * 256);
+        for (int g = 0; g < PG; g++) a[0][g] = *reinterpret_cast<const f32x4 *>(arow + g * 1600);
+#pragma unroll
+        for (int kg = 0; kg < GPQ; kg++) {
+            if (kg + 1 < GPQ) {
+#pragma unroll
+                for (int g = 0; g < PG; g++) a[(kg + 1) & 1][g] = *reinterpret_cast<const f32x4 *>(arow + g * 1600 + (kg + 1) * 4);
+            }
+            if (kg + PDG < GPQ) {
+#pragma unroll
+                for (int t = 0; t < TPW; t++) bq[(kg + PDG) % (PDG + 1)][t] = wb.load(woff[t] + (kg + PDG) * 256);
             }
 #pragma unroll
-            for (int i = 0; i < NTW; i++) {
-                if (i + 1 < NTW || valid[i]) {                          // only a wave's LAST tile can be empty
+            for (int t = 0; t < TPW; t++) {
+                if (t + 1 < TPW || valid[t]) {                          // only a wave's LAST tile can be empty
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[kb % PD][i][j], a[kb & 1][j], acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < PG; g++)
+                            acc[t][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[kg & 1][g][j], bq[kg % (PDG + 1)][t][j], acc[t][g], 0, 0, 0);
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < NTW; i++) {
-            const int nt = wave + NW * i;
-            if (valid[i] && l15 < NB)
-                *reinterpret_cast<f32x4 *>(&lg[l15 * NPOL_PAD + nt * 16 + 4 * q]) = acc[i] + bias4(LAY.pf_b + nt * 16);
+        for (int t = 0; t < TPW; t++) {
+            if (valid[t]) {
+                const int T = th * TPW + t;
+#pragma unroll
+                for (int g = 0; g < PG; g++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) part[(kq * NB + 4 * g + r) * 320 + T * 64 + lane] = acc[t][g][r];
+            }
         }
+    }
+    __syncthreads();
+    for (int i = tid; i < NB * NPOL; i += NTH) {
+        const int s = i / NPOL, col = i - s * NPOL;
+        const float q0 = part[(0 * NB + s) * 320 + col], q1 = part[(1 * NB + s) * 320 + col], q2 = part[(2 * NB + s) * 320 + col],
+                    q3 = part[(3 * NB + s) * 320 + col];
+        lg[s * NPOL_PAD + col] = ((q0 + q1) + q2) + q3 + W[LAY.pf_b + col];
     }
     // ---- value head, part 2: dense 25 -> 32 ReLU (thread = (position, unit)), then 32 -> 1 tanh ---------
     float *h1 = S.y2 + 256 + NB * NPOL_PAD;              // [NB][32]
@@ -680,7 +707,14 @@ int ccsp_net_pack(const float *plain, float *packed) {
     }
     { std::vector<float> Wkn(p, p + 64 * 16); pack_gemm(Wkn, 64, 16, 4, 1, packed + LAY.pc_w); p += 1024; }
     memcpy(packed + LAY.pc_b, p, 16 * sizeof(float)); p += 16;
-    { std::vector<float> Wkn(p, p + 400 * 294); pack_gemm(Wkn, 400, 294, 25, 19, packed + LAY.pf_w); p += 117600; }      // row (h*5+w)*16 + c = pc's own order
+    for (int T = 0; T < 5; T++)                                            // policy dense: row k = (h*5+w)*16 + c = pc's own order
+        for (int g = 0; g < 100; g++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 4; j++) {
+                    const int k = 4 * g + j, col = 64 * T + lane;
+                    packed[LAY.pf_w + ((T * 100 + g) * 64 + lane) * 4 + j] = col < 294 ? p[(size_t)k * 294 + col] : 0.0f;
+                }
+    p += 117600;
     memcpy(packed + LAY.pf_b, p, 294 * sizeof(float)); p += 294;
     memcpy(packed + LAY.vc_w, p, 64 * sizeof(float)); p += 64;
     packed[LAY.vc_b] = *p; p += 1;
