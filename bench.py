@@ -231,9 +231,9 @@ def config3(args, torch, rank, world, local, barrier):
     p_out = torch.empty((n_pos, 294), dtype=torch.float64, device=x.device)
     v_out = torch.empty(n_pos, dtype=torch.float32, device=x.device)
     st = _stream_ptr()
-    for _ in range(5):
+    for _ in range(100):                    # (a short burst right after an idle gap is timed at whatever clock the part is ramping through)
         L.ccsp_net_forward(packed.data_ptr(), x.data_ptr(), n_pos, None, p_out.data_ptr(), v_out.data_ptr(), st)
-    iters = 50
+    iters = 400
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
