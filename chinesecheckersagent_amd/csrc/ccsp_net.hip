@@ -137,7 +137,7 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
 
 // One GEMM layer for one wave: output tiles (mt0 .. mt0+NMT) x (one 16-column tile nt), K = 16*KB.
 // afrag(mt, kb, i) -> the lane's four A values of k-block kb for row tile mt (i = mt - mt0, a compile-time
-// slot for per-tile precomputed data);  epi(mt, acc) consumes a tile (bias, residual, ReLU: the bias is added AFTER the
+// slot for per-tile precomputed data);  epi(mt, acc, i) consumes a tile (i = mt - mt0, static after unrolling) (bias, residual, ReLU: the bias is added AFTER the
 // sum as Keras does -- starting the accumulator from it costs accuracy: 2.6e-5 instead of 1.5e-5 worst logit).  wbase = float offset of the layer's packed weights.
 // No tile is ever skipped: where two waves share an odd number of tiles, both compute the middle one.
 // Register discipline of both loops (every index is static after unrolling): the A fragments of k-block kb live in
@@ -186,7 +186,7 @@ __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, in
     }
     next();
 #pragma unroll
-    for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i]);
+    for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i], i);
 }
 
 // The 32-column layers have 13 x 2 = 26 tile jobs for 8 waves.  Instead of four jobs on every wave (two of the
@@ -245,7 +245,7 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
         f32x4 sum = acc[i][0];
 #pragma unroll
         for (int c = 1; c < NSPLIT; c++) sum = sum + acc[i][c];          // the order in which the shared tile's partial sums are added up by its consumer
-        epi(mt0 + i, sum);
+        epi(mt0 + i, sum, i);
     }
     *reinterpret_cast<f32x4 *>(&part[lane * 4]) = accx;                 // D-fragment order: [lane][reg]
 }
@@ -294,7 +294,7 @@ __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int n
     }
     next();
 #pragma unroll
-    for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i]);
+    for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i], i);
     if (mine) epix(acc[NMT]);
 }
 
@@ -358,6 +358,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     auto bias4 = [&](int off) -> f32x4 { return *reinterpret_cast<const f32x4 *>(W + off + 4 * q); };   // this lane's four output channels
     auto relu4 = [](const f32x4 &v) -> f32x4 { return f32x4{relu(v[0]), relu(v[1]), relu(v[2]), relu(v[3])}; };
 
+    // The trunk's tiles have the same owner in the stem and in every block's last layer (column tile wave & 3, row tiles 6 (wave >> 2)
+    // .. + 6): the owner keeps its seven tiles in registers as well, so that the residual add needs no LDS read.
+    f32x4 xr[7];
     // ---- stem: 3x3 valid, K = 9 taps x 8 -> 5 k-blocks of 2 taps (10th tap = zero weights) -----------
     // A row's nine taps are plain offsets from its top-left input cell (valid convolution); rows past the 200th and the
     // zero-weight 10th tap read staged zeros.  No masks in the loop.
@@ -380,8 +383,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             return *reinterpret_cast<const f32x4 *>(&in[sbase[i] + tapoff[kb]]);
         };
         const f32x4 bv = bias4(LAY.stem_b + nt * 16);
-        auto epi = [&](int mt, const f32x4 &acc) {
-            *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = relu4(acc + bv);
+        auto epi = [&](int mt, const f32x4 &acc, int i) {
+            xr[i] = relu4(acc + bv);
+            *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
         };
         prefetch<5>(wb, LAY.stem_w, nt, pre);
         gemm_tiles<7, 5>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
@@ -425,8 +429,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
             };
             const f32x4 bv = bias4(LAY.l1_b[blk] + nt2 * 16);
-            auto epi = [&](int mt, const f32x4 &acc) {
-                const int i = mt - mt3;
+            auto epi = [&](int, const f32x4 &acc, int i) {
                 *reinterpret_cast<f32x4 *>(&S.y1[(i == 0 ? prow[0] : (i == 1 ? prow[1] : prow[2])) + nt2 * 16]) = relu4(acc + bv);
             };
             auto epix = [&](const f32x4 &acc) {                                 // the last tile: its real rows only
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 return *reinterpret_cast<const f32x4 *>(&S.y1[a3[i] + ((tap / 3) * 6 + tap % 3) * LDY + (kb & 1) * 16]);
             };
             const f32x4 bv = bias4(LAY.l2_b[blk] + nt2 * 16);
-            auto epi = [&](int mt, const f32x4 &acc) {
+            auto epi = [&](int mt, const f32x4 &acc, int i) {
                 *reinterpret_cast<f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + nt2 * 16 + 4 * q]) = relu4(acc + bv);
             };
             gemm_tiles_split<3, 18, NSPLIT>(wb, LAY.l2_w[blk], nt2, mt3, MT - 1, qr, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
@@ -479,10 +482,10 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 return *reinterpret_cast<const f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + kb * 16 + 4 * q]);
             };
             const f32x4 bv = bias4(LAY.l3_b[blk] + nt * 16);
-            auto epi = [&](int mt, const f32x4 &acc) {
-                if (half && mt == 6) return;                                    // ... and updated (read-modify-write) by the first only
-                f32x4 *px = reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]);
-                *px = relu4(acc + bv + *px);                                    // add([x, block_input]) then ReLU
+            auto epi = [&](int mt, const f32x4 &acc, int i) {
+                xr[i] = relu4(acc + bv + xr[i]);                                // add([x, block_input]) then ReLU; the input from registers
+                if (half && mt == 6) return;                                    // ... and stored by the first half only
+                *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
             };
             gemm_tiles<7, 2>(wb, LAY.l3_w[blk], nt, mt0, pre, afrag, [&]() {
                 if (blk < 8) prefetch<4>(wb, LAY.l1_w[blk < 8 ? blk + 1 : 8], nt2, pre);
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
         };
         const f32x4 bv = bias4(LAY.pc_b);
-        auto epi = [&](int mt, const f32x4 &acc) {
+        auto epi = [&](int mt, const f32x4 &acc, int i) {
             *reinterpret_cast<f32x4 *>(&pc[(mt * 16 + l15) * 16 + 4 * q]) = relu4(acc + bv);
         };
         gemm_tiles<2, 4>(wb, LAY.pc_w, 0, mt0, pre, afrag, []() {}, epi);
