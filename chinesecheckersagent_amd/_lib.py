@@ -72,6 +72,7 @@ _SIGS = {
     'ccsp_root_expand': (C.c_int, [_VP, _VP, _VP, _VP]),
     'ccsp_select': (C.c_int, [_VP, _VP, _VP]),
     'ccsp_expand_backup': (C.c_int, [_VP, _VP, _VP, _VP]),
+    'ccsp_expand_backup_select': (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     'ccsp_ply_end': (C.c_int, [_VP, _VP]),
     'ccsp_read_counters': (C.c_int, [_VP, _VP]),
     'ccsp_read_visit_histogram': (C.c_int, [_VP, _VP]),

@@ -1251,10 +1251,7 @@ __global__ __launch_bounds__(64) void root_expand_kernel(Params P, const double 
 }
 
 // stepped path, phase 3: selection; leaf planes out; hand-off record for expand_backup
-__global__ __launch_bounds__(64) void select_kernel(Params P, float *planes) {
-    __shared__ Lds lds;
-    __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch (stepped path): the short tree kernels go first, the next evaluator launch waits for them
-    const int g = blockIdx.x;
+__device__ __forceinline__ void select_core(const Params &P, Lds &lds, int g, float *planes) {
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING || no_search(P, sl) || sl.sim >= (uint32_t)P.sims) {
         if (lane_id() == 0) P.pend[g].kind = 0;
@@ -1278,11 +1275,14 @@ __global__ __launch_bounds__(64) void select_kernel(Params P, float *planes) {
     if (lf.kind == 1) wave_encode(lds, lf.st, lf.player, planes + (uint64_t)g * CCSP_PLANES);
 }
 
-// stepped path, phase 4: expansion with (p, v) + backup
-__global__ __launch_bounds__(64) void expand_backup_kernel(Params P, const double *p, const float *v) {
+__global__ __launch_bounds__(64) void select_kernel(Params P, float *planes) {
     __shared__ Lds lds;
     __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch (stepped path): the short tree kernels go first, the next evaluator launch waits for them
-    const int g = blockIdx.x;
+    select_core(P, lds, blockIdx.x, planes);
+}
+
+// stepped path, phase 4: expansion with (p, v) + backup
+__device__ __forceinline__ void expand_backup_core(const Params &P, Lds &lds, int g, const double *p, const float *v) {
     Pending pd;
     {
         const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(P.pend + g);
@@ -1316,6 +1316,22 @@ __global__ __launch_bounds__(64) void expand_backup_kernel(Params P, const doubl
     sl.sim += 1;
     store_slot(P.slots + g, sl);
     if (lane_id() == 0) P.pend[g].kind = 0;            // consumed: a repeated call is a no-op
+}
+
+__global__ __launch_bounds__(64) void expand_backup_kernel(Params P, const double *p, const float *v) {
+    __shared__ Lds lds;
+    __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch (stepped path): the short tree kernels go first, the next evaluator launch waits for them
+    expand_backup_core(P, lds, blockIdx.x, p, v);
+}
+
+// phases 4 and 3 of consecutive simulations in one launch: expansion + backup of simulation s, then the selection of s + 1 (the
+// same wave, the same game) -- inside a ply the stepped loop is [evaluate -> this] instead of [evaluate -> expand_backup -> select]
+__global__ __launch_bounds__(64) void expand_backup_select_kernel(Params P, const double *p, const float *v, float *planes) {
+    __shared__ Lds lds;
+    __builtin_amdgcn_s_setprio(2);
+    expand_backup_core(P, lds, blockIdx.x, p, v);
+    __syncthreads();                                   // the slot record, the pool and the hand-off record: stores before loads
+    select_core(P, lds, blockIdx.x, planes);
 }
 
 // stepped path, phase 5: pi, sampling, move, rules (or the random opening move)
@@ -1602,6 +1618,15 @@ int ccsp_expand_backup(ccsp_ctx *ctx, const double *p, const float *v, void *str
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 2;
     return CCSP_OK;
+}
+
+int ccsp_expand_backup_select(ccsp_ctx *ctx, const double *p, const float *v, float *planes, void *stream) {
+    if (!ctx || !p || !v || !planes) return CCSP_EINVAL;
+    if (ctx->phase != 3) return CCSP_ESTATE;
+    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    hipLaunchKernelGGL(expand_backup_select_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes);
+    CCSP_HIPCHK(hipGetLastError());
+    return CCSP_OK;                                        // phase stays 3: the next simulation's leaves are waiting for (p, v)
 }
 
 int ccsp_ply_end(ccsp_ctx *ctx, void *stream) {

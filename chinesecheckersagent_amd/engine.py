@@ -84,6 +84,12 @@ class SelfPlayEngine(object):
         self._check_pv(p, v)
         check(self.L.ccsp_expand_backup(self.ctx, p.data_ptr(), v.data_ptr(), _stream_ptr(stream)), 'ccsp_expand_backup')
 
+    def expand_backup_select(self, p, v, planes, stream=None):
+        """expand_backup(p, v) and the next simulation's select(planes) in one launch"""
+        self._check_pv(p, v)
+        check(self.L.ccsp_expand_backup_select(self.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(), _stream_ptr(stream)),
+              'ccsp_expand_backup_select')
+
     def ply_end(self, stream=None):
         check(self.L.ccsp_ply_end(self.ctx, _stream_ptr(stream)), 'ccsp_ply_end')
 

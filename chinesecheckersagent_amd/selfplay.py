@@ -109,12 +109,15 @@ class BatchSelfPlay(object):
                 selected = False
                 keep = []
                 with torch.cuda.graph(g):                      # capture only: nothing executes here
-                    for _ in range(self._unroll):
-                        e.select(self.planes)
-                        selected = True
+                    e.select(self.planes)
+                    selected = True
+                    for i in range(self._unroll):              # [evaluate -> expand/backup + the next selection] in one tree launch
                         gp, gv = self._evaluate(root_is_p2)
-                        e.expand_backup(gp, gv)
-                        selected = False
+                        if i + 1 < self._unroll:
+                            e.expand_backup_select(gp, gv, self.planes)
+                        else:
+                            e.expand_backup(gp, gv)
+                            selected = False
                         keep.append((gp, gv))
                 self._graph = g
                 self._graph_out = keep                         # keep the captured outputs alive
@@ -127,10 +130,13 @@ class BatchSelfPlay(object):
             for _ in range(self.sims // self._unroll):
                 self._graph.replay()
         else:
-            for _ in range(self.sims):
-                e.select(self.planes)
+            e.select(self.planes)
+            for i in range(self.sims):
                 p, v = self._evaluate(root_is_p2)
-                e.expand_backup(p, v)
+                if i + 1 < self.sims:
+                    e.expand_backup_select(p, v, self.planes)
+                else:
+                    e.expand_backup(p, v)
         e.ply_end()
 
     def run_to_completion(self, max_plies=2048):

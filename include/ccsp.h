@@ -225,6 +225,9 @@ int ccsp_ply_begin(ccsp_ctx *ctx, float *planes, void *stream);
 int ccsp_root_expand(ccsp_ctx *ctx, const double *p, const float *v, void *stream);
 int ccsp_select(ccsp_ctx *ctx, float *planes, void *stream);
 int ccsp_expand_backup(ccsp_ctx *ctx, const double *p, const float *v, void *stream);
+/* ccsp_expand_backup followed by ccsp_select in ONE launch (inside a ply: [evaluate -> this] per simulation instead of
+ * [evaluate -> expand_backup -> select]); same results */
+int ccsp_expand_backup_select(ccsp_ctx *ctx, const double *p, const float *v, float *planes, void *stream);
 int ccsp_ply_end(ccsp_ctx *ctx, void *stream);
 
 /* ---- evaluator: the policy/value network as one fused kernel (row N1; Model.predict, model.py:21-24) ---- */

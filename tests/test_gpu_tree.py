@@ -109,12 +109,12 @@ def _table_eval(ev, pos12, player):
 def test_stepped_search_matches_reference(eng, golden_dir):
     """the same cases at sims = 50 through the external-evaluator path: ply_begin -> root_expand ->
     50 x (select -> expand_backup) -> ply_end, with (p, v) computed on the host from the PLANES the
-    kernels emit (so the encode path is covered as well)"""
+    kernels emit (so the encode path is covered as well); and the same with expand_backup and the next select in one launch"""
     import torch
     from chinesecheckersagent_amd import _lib
     doc = json.load(open(golden_dir + '/tree.json'))
     seed, cases = doc['seed'], doc['cases']
-    for (sims, ev), idxs in sorted(_groups(cases).items()):
+    for ((sims, ev), idxs), merged in [(g, m) for g in sorted(_groups(cases).items()) for m in (False, True)]:
         if sims != 50:
             continue
         n = len(idxs)
@@ -141,17 +141,26 @@ def test_stepped_search_matches_reference(eng, golden_dir):
         e.ply_begin(planes)
         evaluate()
         e.root_expand(p, v)
-        for _ in range(sims):
+        if merged:                       # expand_backup + the next simulation's select in one launch (ccsp_expand_backup_select)
             e.select(planes)
-            evaluate()
-            e.expand_backup(p, v)
+            for i in range(sims):
+                evaluate()
+                if i + 1 < sims:
+                    e.expand_backup_select(p, v, planes)
+                else:
+                    e.expand_backup(p, v)
+        else:
+            for _ in range(sims):
+                e.select(planes)
+                evaluate()
+                e.expand_backup(p, v)
         e.ply_end()
         st, meta, pi = e.log()
         row_of = {int(m['game']): r for r, m in enumerate(meta)}
         slots = e.slots()
         assert e.counters()['errors'] == 0
         for s, c in enumerate(cs):
-            tag = 'stepped case %d (ev=%d)' % (idxs[s], ev)
+            tag = 'stepped case %d (ev=%d, merged=%s)' % (idxs[s], ev, merged)
             r = row_of[c['game']]
             _check_case(c, e.read_root(s), pi[r], e.tree_digest(s), slots['state'][s]['pos'].reshape(12), tag)
         e.close()
