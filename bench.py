@@ -200,7 +200,7 @@ def config3(args, torch, rank, world, local, barrier):
     if w:
         model.load_weights(w)
     warm, timed = args.net_warmup_plies, args.net_plies
-    parts = 2 if (G >= 2048 and G % 2 == 0) else 1
+    parts = int(os.environ.get('CCSP_BENCH_PARTS', '0')) or (2 if (G >= 2048 and G % 2 == 0) else 1)   # (the override is a measurement aid)
     total = warm + timed + 8
     if parts > 1:
         b = sp.PipelinedSelfPlay(model, n_slots=G, n_parts=parts, sims=S, seed=SEED, first_game=rank, game_stride=world,
