@@ -349,6 +349,13 @@ def test_c_abi_error_paths(eng):
     e.play_plies(_lib.EVAL_HASH, 1)
     assert e.counters()['errors'] == 0 and e.log_size() == 4
     assert L.ccsp_set_positions(e.ctx, None, None, None, None, None, None) == _lib.EINVAL
+    # the stepped entry points refuse to be called out of order (no simulation is selected yet) and with missing arguments
+    planes = torch.zeros((4, 343), dtype=torch.float32, device='cuda')
+    p = torch.zeros((4, 294), dtype=torch.float64, device='cuda'); v = torch.zeros(4, dtype=torch.float32, device='cuda')
+    ESTATE = _lib.ESTATE
+    assert L.ccsp_expand_backup(e.ctx, p.data_ptr(), v.data_ptr(), None) == ESTATE
+    assert L.ccsp_expand_backup_select(e.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(), None) == ESTATE
+    assert L.ccsp_expand_backup_select(e.ctx, p.data_ptr(), v.data_ptr(), None, None) == _lib.EINVAL
     e.close()
 
 
