@@ -38,6 +38,16 @@ for k, x in d.items():
                     vgpr=x['vgpr'], lds_bytes=x['lds_bytes'],
                     workload='4096 games x 400 simulations, config 2a; launches of FOUR plies, every figure here divided by four = per ply',
                     source=src)
+    elif k.startswith('net_forward_kernel') and 'Cfg<8, 8>' in k:
+        c['net_forward_kernel'] = dict(n=x['grid_threads'] // 64, fetch_size_kb=x['FETCH_SIZE'], write_size_kb=x['WRITE_SIZE'],
+                                       mfma_insts=x['SQ_INSTS_VALU_MFMA_F32'], mfma_busy_cycles=x['SQ_VALU_MFMA_BUSY_CYCLES'],
+                                       grbm_gui_active=x['GRBM_GUI_ACTIVE'],
+                                       mfma_busy_frac=x['SQ_VALU_MFMA_BUSY_CYCLES'] / (x['GRBM_GUI_ACTIVE'] * 128.0),   # 1024 SIMDs / 8 XCD clocks
+                                       insts_valu=x['SQ_INSTS_VALU'], insts_salu=x['SQ_INSTS_SALU'], insts_lds=x['SQ_INSTS_LDS'],
+                                       lds_bank_conflict=x['SQ_LDS_BANK_CONFLICT'], lds_idx_active=x['SQ_LDS_IDX_ACTIVE'],
+                                       wait_inst_lds_quad=x['SQ_WAIT_INST_LDS'], wave_cycles_quad=x['SQ_WAVE_CYCLES'],
+                                       wait_any_quad=x['SQ_WAIT_ANY'], wait_inst_any_quad=x['SQ_WAIT_INST_ANY'],
+                                       launch_ms_under_pmc=x['launch_us_under_pmc']['SQ_VALU_MFMA_BUSY_CYCLES'] / 1e3, vgpr=x['vgpr'], source=src)
     else:
         continue
     print('updated', k)
