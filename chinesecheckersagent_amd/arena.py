@@ -60,12 +60,15 @@ class BatchArena(object):
             g = torch.cuda.CUDAGraph()
             keep = []
             with torch.cuda.graph(g):
-                for _ in range(self._unroll):
-                    e.select(self.planes)
-                    selected = True
+                e.select(self.planes)
+                selected = True
+                for i in range(self._unroll):             # [forward(s) -> expand/backup + the next selection] in one tree launch
                     gp, gv = self._evaluate(root_is_p2)
-                    e.expand_backup(gp, gv)
-                    selected = False
+                    if i + 1 < self._unroll:
+                        e.expand_backup_select(gp, gv, self.planes)
+                    else:
+                        e.expand_backup(gp, gv)
+                        selected = False
                     keep.append((gp, gv))
             self._graph, self._graph_out = g, keep
         except Exception:
@@ -86,11 +89,14 @@ class BatchArena(object):
         if self._graph is not None:
             for _ in range((self.sims - 1) // self._unroll):
                 self._graph.replay()
-        else:
-            for _ in range(self.sims - 1):
-                e.select(self.planes)
+        elif self.sims > 1:
+            e.select(self.planes)
+            for i in range(self.sims - 1):
                 p, v = self._evaluate(root_is_p2)
-                e.expand_backup(p, v)
+                if i + 2 < self.sims:
+                    e.expand_backup_select(p, v, self.planes)
+                else:
+                    e.expand_backup(p, v)
         e.ply_end()
 
     def run(self, max_moves=4096):
