@@ -78,6 +78,7 @@ _SIGS = {
     'ccsp_read_visit_histogram': (C.c_int, [_VP, _VP]),
     'ccsp_read_slots': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'ccsp_log_size': (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    'ccsp_log_clear': (C.c_int, [_VP, _VP]),
     'ccsp_log_device_ptrs': (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     'ccsp_read_log': (C.c_int, [_VP, C.c_uint64, C.c_uint64, _VP, _VP, _VP]),
     'ccsp_read_results': (C.c_int, [_VP, C.c_uint64, C.c_uint64, _VP]),

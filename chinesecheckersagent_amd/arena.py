@@ -9,23 +9,26 @@ import numpy as np
 from . import _lib
 from .config import DET_TREE_TAU, MCTS_SIMULATIONS
 from .engine import SelfPlayEngine
-from .selfplay import _batched, _default_seed
+from .selfplay import _batched, _default_seed, _strict, _warn
 
 
 class BatchArena(object):
     def __init__(self, model1, model2, n_games, sims=MCTS_SIMULATIONS, seed=None, first_game=0, tree_tau=DET_TREE_TAU,
-                 enforce_move_limit=False, alternate=False, device=0, greedy=0, use_graph=True):
+                 enforce_move_limit=False, alternate=False, device=0, greedy=0, use_graph=True, game_stride=1, index0=0):
+        """game k of this batch is game index0 + k * game_stride of the match (id first_game + k * game_stride): a rank of an
+        N-GPU match passes first_game = base + rank, game_stride = N, index0 = rank"""
         import torch
         self.torch = torch
         self.m1, self.m2 = _batched(model1), _batched(model2 if model2 is not None else model1)
         self.eng = SelfPlayEngine(n_slots=n_games, sims=sims, seed=_default_seed[0] if seed is None else seed,
-                                  first_game=first_game, max_games=n_games, log_capacity=n_games * 1024, device=device,
-                                  arena=True, arena_det_tau=(tree_tau == DET_TREE_TAU), enforce_move_limit=enforce_move_limit,
+                                  first_game=first_game, game_stride=game_stride, max_games=n_games, log_capacity=n_games * 1024,
+                                  device=device, arena=True, arena_det_tau=(tree_tau == DET_TREE_TAU),
+                                  enforce_move_limit=enforce_move_limit,
                                   greedy=greedy)         # next-4: GreedyPlayer seats (_lib.GREEDY_*) move without a search
         dev = torch.device('cuda', device)
         self.planes = torch.zeros((n_games, 7, 7, 7), dtype=torch.float32, device=dev)
-        # evaluate_models.py:37-41: odd games swap colours (model2 plays player one)
-        swap = (np.arange(n_games) % 2 == 1) if alternate else np.zeros(n_games, dtype=bool)
+        # evaluate_models.py:37-41: odd games of the match swap colours (model2 plays player one)
+        swap = ((index0 + np.arange(n_games) * game_stride) % 2 == 1) if alternate else np.zeros(n_games, dtype=bool)
         self.swap = torch.from_numpy(swap).to(dev)
         self.swap_host = swap
         self.n_games, self.sims = n_games, sims
@@ -71,11 +74,14 @@ class BatchArena(object):
                         selected = False
                     keep.append((gp, gv))
             self._graph, self._graph_out = g, keep
-        except Exception:
+        except Exception as ex:
             self.use_graph, self._graph = False, None
             if selected:                                  # close the half-captured step on the host side
                 p, v = self._evaluate(root_is_p2)
                 e.expand_backup(p, v)
+            if _strict():
+                raise
+            _warn('hipGraph capture of the arena\'s simulation steps failed (%r): this match runs on plain launches' % (ex,))
 
     def play_move(self):
         e = self.eng
@@ -138,31 +144,42 @@ def agent_match(model1, model2, num_games, verbose=False, tree_tau=DET_TREE_TAU,
 
 
 def evaluate(model1, model2, num_games, enforce_move_limit=False, sims=MCTS_SIMULATIONS, seed=None, first_game=0,
-             tree_tau=DET_TREE_TAU):
+             tree_tau=DET_TREE_TAU, dist=None, device=0):
     """evaluate_models.evaluate (evaluate_models.py:10-53) / train.evaluate (train.py:150-186, which passes
-    enforce_move_limit=True): colours alternate with the game index; returns (model1 wins, model2 wins, draws)."""
-    m1, m2 = _load(model1), _load(model2)
-    b = BatchArena(m1, m2, num_games, sims=sims, seed=seed, first_game=first_game, tree_tau=tree_tau,
-                   enforce_move_limit=enforce_move_limit, alternate=True)
-    try:
-        winners, _ = b.run()
-    finally:
-        b.close()
+    enforce_move_limit=True): colours alternate with the game index; returns (model1 wins, model2 wins, draws).
+    With a process group (`dist`: evaluate_in_parallel, evaluate_models.py:57-102, one rank per GPU) rank r plays the games
+    r, r + R, ... of the match and the three counts meet in one all-reduce: every rank returns the match's totals."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    mine = len(range(rank, num_games, world))
     w1 = w2 = d = 0
-    for i, w in enumerate(winners):
-        if w is None:
-            d += 1
-        elif (w == 1) != bool(b.swap_host[i]):
-            w1 += 1
-        else:
-            w2 += 1
+    if mine > 0:
+        m1, m2 = _load(model1, device), _load(model2, device)
+        b = BatchArena(m1, m2, mine, sims=sims, seed=seed, first_game=first_game + rank, tree_tau=tree_tau,
+                       enforce_move_limit=enforce_move_limit, alternate=True, device=device, game_stride=world, index0=rank)
+        try:
+            winners, _ = b.run()
+        finally:
+            b.close()
+        for i, w in enumerate(winners):
+            if w is None:
+                d += 1
+            elif (w == 1) != bool(b.swap_host[i]):
+                w1 += 1
+            else:
+                w2 += 1
+    if dist is not None:
+        import torch
+        from .launch import coll_device
+        t = torch.tensor([w1, w2, d], dtype=torch.int64, device=coll_device(dist))
+        dist.all_reduce(t)
+        w1, w2, d = (int(x) for x in t.cpu())
     return w1, w2, d
 
 
-def _load(model):
+def _load(model, device=None):
     if isinstance(model, str):                             # load_agent (ai_vs_ai.py:15-25)
         from .model import ResidualCNN
-        m = ResidualCNN()
+        m = ResidualCNN(device=None if device is None else 'cuda:%d' % device)
         m.load_weights(model)
         return m
     return model

@@ -710,7 +710,7 @@ __device__ __forceinline__ void slot_finish(const Params &P, Lds &lds, Slot &sl,
         const uint64_t w0 = (uint64_t)(uint32_t)status | ((uint64_t)reward << 8) | ((uint64_t)(sl.ply & 0xFFFF) << 16) | ((uint64_t)sl.n_hist << 32);
         *reinterpret_cast<ulonglong2 *>(P.results + sl.index) = make_ulonglong2(w0, sl.expansions);
     }
-    if (P.auto_restart) slot_restart(P, lds, sl);
+    if (P.auto_restart && !bad) slot_restart(P, lds, sl);      // after an ERROR (sample log full, ply cap) the slot stays out of play
 }
 
 // selfplay.py:38-74 after a ply was played: `moved` = (from, to) by sl.player on sl.st -> updates sl
@@ -767,7 +767,7 @@ __device__ __forceinline__ void slot_after_move(const Params &P, Lds &lds, Slot 
             const uint64_t w0 = (uint64_t)(uint32_t)status | ((uint64_t)reward << 8) | ((uint64_t)(sl.ply & 0xFFFF) << 16) | ((uint64_t)sl.n_hist << 32);
             *reinterpret_cast<ulonglong2 *>(P.results + sl.index) = make_ulonglong2(w0, sl.expansions);
         }
-        if (P.auto_restart) slot_restart(P, lds, sl);
+        if (P.auto_restart && !bad) slot_restart(P, lds, sl);
     }
 }
 
@@ -1421,13 +1421,30 @@ struct ccsp_ctx {
 
 // Every entry point runs on the context's own device, whatever the caller's current device is, and refuses a
 // stream that belongs to another device (a launch there would fail with an invalid resource handle).
-static int ctx_enter(const ccsp_ctx *ctx, void *stream);
+// The caller's current device is put back when the entry point returns (a process that holds several devices keeps its
+// torch.cuda.current_device() across eng.counters() / close()).
+struct ctx_scope {
+    int prev = -1, rc = CCSP_OK;
+    ctx_scope(const ccsp_ctx *ctx, void *stream) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != ctx->cfg.device && hipSetDevice(ctx->cfg.device) != hipSuccess) { rc = CCSP_EHIP; (void)hipGetLastError(); return; }
+        if (stream) {
+            hipDevice_t sd = -1;
+            if (hipStreamGetDevice((hipStream_t)stream, &sd) != hipSuccess) { rc = CCSP_EINVAL; (void)hipGetLastError(); }
+            else if ((int)sd != ctx->cfg.device) rc = CCSP_EINVAL;
+        }
+    }
+    ctx_scope(const ctx_scope &) = delete;
+    ctx_scope &operator=(const ctx_scope &) = delete;
+    ~ctx_scope() { if (prev >= 0 && prev != -1) { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev); } }
+};
+#define CTX_ENTER(ctx, stream) ctx_scope scope_((ctx), (stream)); if (scope_.rc != CCSP_OK) return scope_.rc
 
 extern "C" {
 
 int ccsp_destroy(ccsp_ctx *ctx) {
     if (!ctx) return CCSP_OK;
-    (void)ctx_enter(ctx, nullptr);
+    ctx_scope scope_(ctx, nullptr);
     Params &P = ctx->P;
     void *ptrs[] = {P.slots, P.pend, P.pool, P.path, ctx->sqrt_tab, ctx->pow_tab, ctx->rcp_tab, P.counters, P.stepacc, P.visit_hist,
                     P.log_state, P.log_meta, P.log_pi, P.log_count, P.results};
@@ -1436,7 +1453,18 @@ int ccsp_destroy(ccsp_ctx *ctx) {
     return CCSP_OK;
 }
 
+static ccsp_ctx *create_on_device(const ccsp_config *cfg, int *err);
+
 ccsp_ctx *ccsp_create(const ccsp_config *cfg, int *err) {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+    ccsp_ctx *ctx = create_on_device(cfg, err);
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);   // the caller's device stays current
+    return ctx;
+}
+
+static ccsp_ctx *create_on_device(const ccsp_config *cfg, int *err) {
     if (err) *err = CCSP_OK;
     if (!cfg || cfg->n_slots <= 0 || cfg->sims <= 0 || cfg->sims > 4000 || cfg->game_stride == 0 || cfg->max_games == 0 ||
         cfg->mode < CCSP_MODE_SELFPLAY || cfg->mode > CCSP_MODE_GREEDY_DATA || cfg->greedy < 0 || cfg->greedy > 15 || cfg->stuck_limit < 0 ||
@@ -1506,7 +1534,7 @@ int ccsp_reset(ccsp_ctx *ctx, void *stream) {
     if (!ctx) return CCSP_EINVAL;
     Params &P = ctx->P;
     hipStream_t s = (hipStream_t)stream;
-    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, stream);
     CCSP_HIPCHK(hipMemsetAsync(P.counters, 0, CCSP_CNT_COUNT * sizeof(unsigned long long), s));
     CCSP_HIPCHK(hipMemsetAsync(P.stepacc, 0, (size_t)P.n_slots * 8 * sizeof(uint32_t), s));
     CCSP_HIPCHK(hipMemsetAsync(P.visit_hist, 0, CCSP_NUM_ACTIONS * sizeof(unsigned long long), s));
@@ -1525,7 +1553,7 @@ int ccsp_set_positions(ccsp_ctx *ctx, const ccsp_state *states, const uint8_t *p
     const Params &P = ctx->P;
     hipStream_t s = (hipStream_t)stream;
     const size_t G = (size_t)P.n_slots;
-    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, stream);
     // staging buffers are released on every way out (ccsp_devbuf), allocation failure is CCSP_ENOMEM
     ccsp_devbuf d_states, d_player, d_game, d_ply, d_tau;
     CCSP_ALLOCCHK(hipMalloc(&d_states.p, G * sizeof(ccsp_state)));
@@ -1553,7 +1581,7 @@ int ccsp_debug_plies_per_launch(int n) { const int was = g_plies_per_launch; if 
 int ccsp_play_plies(ccsp_ctx *ctx, int evaluator, int n_plies, void *stream) {
     if (!ctx || n_plies < 0 || evaluator < 0 || evaluator > CCSP_EVAL_ROLLOUT) return CCSP_EINVAL;
     if (n_plies == 0) return CCSP_OK;
-    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, stream);
     if (ctx->P.gen) {                                       // greedy data generator: nothing to search
         hipLaunchKernelGGL(greedy_plies_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, n_plies);
         CCSP_HIPCHK(hipGetLastError());
@@ -1583,7 +1611,7 @@ int ccsp_play_plies(ccsp_ctx *ctx, int evaluator, int n_plies, void *stream) {
 
 int ccsp_ply_begin(ccsp_ctx *ctx, float *planes, void *stream) {
     if (!ctx || !planes) return CCSP_EINVAL;
-    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, stream);
     hipLaunchKernelGGL(ply_begin_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, planes);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 1;
@@ -1593,7 +1621,7 @@ int ccsp_ply_begin(ccsp_ctx *ctx, float *planes, void *stream) {
 int ccsp_root_expand(ccsp_ctx *ctx, const double *p, const float *v, void *stream) {
     if (!ctx || !p || !v) return CCSP_EINVAL;
     if (ctx->phase != 1) return CCSP_ESTATE;
-    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, stream);
     hipLaunchKernelGGL(root_expand_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 2;
@@ -1603,7 +1631,7 @@ int ccsp_root_expand(ccsp_ctx *ctx, const double *p, const float *v, void *strea
 int ccsp_select(ccsp_ctx *ctx, float *planes, void *stream) {
     if (!ctx || !planes) return CCSP_EINVAL;
     if (ctx->phase != 2) return CCSP_ESTATE;
-    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, stream);
     hipLaunchKernelGGL(select_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, planes);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 3;
@@ -1613,7 +1641,7 @@ int ccsp_select(ccsp_ctx *ctx, float *planes, void *stream) {
 int ccsp_expand_backup(ccsp_ctx *ctx, const double *p, const float *v, void *stream) {
     if (!ctx || !p || !v) return CCSP_EINVAL;
     if (ctx->phase != 3) return CCSP_ESTATE;
-    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, stream);
     hipLaunchKernelGGL(expand_backup_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 2;
@@ -1623,7 +1651,7 @@ int ccsp_expand_backup(ccsp_ctx *ctx, const double *p, const float *v, void *str
 int ccsp_expand_backup_select(ccsp_ctx *ctx, const double *p, const float *v, float *planes, void *stream) {
     if (!ctx || !p || !v || !planes) return CCSP_EINVAL;
     if (ctx->phase != 3) return CCSP_ESTATE;
-    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, stream);
     hipLaunchKernelGGL(expand_backup_select_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes);
     CCSP_HIPCHK(hipGetLastError());
     return CCSP_OK;                                        // phase stays 3: the next simulation's leaves are waiting for (p, v)
@@ -1632,7 +1660,7 @@ int ccsp_expand_backup_select(ccsp_ctx *ctx, const double *p, const float *v, fl
 int ccsp_ply_end(ccsp_ctx *ctx, void *stream) {
     if (!ctx) return CCSP_EINVAL;
     if (ctx->phase != 2 && ctx->phase != 1) return CCSP_ESTATE;
-    { const int rc_ = ctx_enter(ctx, stream); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, stream);
     hipLaunchKernelGGL(ply_end_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P);
     CCSP_HIPCHK(hipGetLastError());
     ctx->phase = 0;
@@ -1644,7 +1672,7 @@ int ccsp_ply_end(ccsp_ctx *ctx, void *stream) {
 
 int ccsp_read_counters(ccsp_ctx *ctx, uint64_t *out /* [CCSP_CNT_COUNT] */) {
     if (!ctx || !out) return CCSP_EINVAL;
-    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
     CCSP_HIPCHK(hipMemcpy(out, ctx->P.counters, CCSP_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
     // plus what the stepped kernels have tallied per slot since the last ply_end
@@ -1659,7 +1687,7 @@ int ccsp_read_counters(ccsp_ctx *ctx, uint64_t *out /* [CCSP_CNT_COUNT] */) {
 
 int ccsp_read_visit_histogram(ccsp_ctx *ctx, uint64_t *out /* [294] */) {
     if (!ctx || !out) return CCSP_EINVAL;
-    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
     CCSP_HIPCHK(hipMemcpy(out, ctx->P.visit_hist, CCSP_NUM_ACTIONS * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return CCSP_OK;
@@ -1667,7 +1695,7 @@ int ccsp_read_visit_histogram(ccsp_ctx *ctx, uint64_t *out /* [294] */) {
 
 int ccsp_read_slots(ccsp_ctx *ctx, uint8_t *status, uint32_t *ply, uint64_t *game, ccsp_state *state, uint8_t *player) {
     if (!ctx) return CCSP_EINVAL;
-    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
     const int G = ctx->P.n_slots;
     std::vector<SlotMem> h((size_t)G);
@@ -1684,11 +1712,20 @@ int ccsp_read_slots(ccsp_ctx *ctx, uint8_t *status, uint32_t *ply, uint64_t *gam
 
 int ccsp_log_size(ccsp_ctx *ctx, uint64_t *n) {
     if (!ctx || !n) return CCSP_EINVAL;
-    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
     unsigned long long c = 0;
     CCSP_HIPCHK(hipMemcpy(&c, ctx->P.log_count, sizeof c, hipMemcpyDeviceToHost));
     *n = c < ctx->P.log_cap ? c : ctx->P.log_cap;
+    return CCSP_OK;
+}
+
+// Rows read so far are given back: the log is empty again (stream-ordered).  A caller that reads the log every H plies and clears it
+// never needs more than n_slots x H rows, however many games the context plays (a slot appends at most one row per ply).
+int ccsp_log_clear(ccsp_ctx *ctx, void *stream) {
+    if (!ctx) return CCSP_EINVAL;
+    CTX_ENTER(ctx, stream);
+    CCSP_HIPCHK(hipMemsetAsync(ctx->P.log_count, 0, sizeof(unsigned long long), (hipStream_t)stream));
     return CCSP_OK;
 }
 
@@ -1702,6 +1739,7 @@ int ccsp_log_device_ptrs(ccsp_ctx *ctx, ccsp_state **state, ccsp_sample_meta **m
 
 int ccsp_read_log(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_state *state, ccsp_sample_meta *meta, double *pi) {
     if (!ctx) return CCSP_EINVAL;
+    CTX_ENTER(ctx, nullptr);
     uint64_t have = 0;
     int rc = ccsp_log_size(ctx, &have);
     if (rc) return rc;
@@ -1715,7 +1753,7 @@ int ccsp_read_log(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_state *state, 
 
 int ccsp_read_results(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_game_result *out) {
     if (!ctx || !out || first + n > ctx->P.max_games) return CCSP_EINVAL;
-    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
     if (n) CCSP_HIPCHK(hipMemcpy(out, ctx->P.results + first, n * sizeof(ccsp_game_result), hipMemcpyDeviceToHost));
     return CCSP_OK;
@@ -1724,7 +1762,7 @@ int ccsp_read_results(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_game_resul
 // root edges of a slot's current tree (valid after a ply was searched, until the next one starts)
 int ccsp_read_root(ccsp_ctx *ctx, int slot, int *k_out, uint32_t *N, double *W, double *Pr, uint16_t *mv) {
     if (!ctx || slot < 0 || slot >= ctx->P.n_slots || !k_out) return CCSP_EINVAL;
-    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
     std::vector<uint8_t> blk(MAX_BLOCK_BYTES);
     CCSP_HIPCHK(hipMemcpy(blk.data(), ctx->P.pool + (uint64_t)slot * ctx->P.pool_stride, MAX_BLOCK_BYTES, hipMemcpyDeviceToHost));
@@ -1761,7 +1799,7 @@ static void digest_block(const uint8_t *pool, uint32_t off, uint64_t &h, uint64_
 
 int ccsp_debug_tree_digest(ccsp_ctx *ctx, int slot, uint64_t *digest, uint64_t *nodes, uint64_t *edges) {
     if (!ctx || slot < 0 || slot >= ctx->P.n_slots || !digest || !nodes || !edges) return CCSP_EINVAL;
-    { const int rc_ = ctx_enter(ctx, nullptr); if (rc_ != CCSP_OK) return rc_; }
+    CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
     std::vector<uint8_t> pool(ctx->P.pool_stride);
     CCSP_HIPCHK(hipMemcpy(pool.data(), ctx->P.pool + (uint64_t)slot * ctx->P.pool_stride, ctx->P.pool_stride, hipMemcpyDeviceToHost));
@@ -1771,13 +1809,3 @@ int ccsp_debug_tree_digest(ccsp_ctx *ctx, int slot, uint64_t *digest, uint64_t *
 }
 
 }  // extern "C"
-
-static int ctx_enter(const ccsp_ctx *ctx, void *stream) {
-    int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->cfg.device) CCSP_HIPCHK(hipSetDevice(ctx->cfg.device));
-    if (stream) {
-        hipDevice_t sd = -1;
-        if (hipStreamGetDevice((hipStream_t)stream, &sd) == hipSuccess && (int)sd != ctx->cfg.device) return CCSP_EINVAL;
-    }
-    return CCSP_OK;
-}

@@ -134,6 +134,10 @@ class SelfPlayEngine(object):
             check(self.L.ccsp_read_log(self.ctx, first, n, state.ctypes.data, meta.ctypes.data, pi.ctypes.data), 'ccsp_read_log')
         return state, meta, pi
 
+    def log_clear(self, stream=None):
+        """forget the rows read so far (stream-ordered): the log is empty again"""
+        check(self.L.ccsp_log_clear(self.ctx, _stream_ptr(stream)), 'ccsp_log_clear')
+
     def log_device_ptrs(self):
         s, m, p = C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(self.L.ccsp_log_device_ptrs(self.ctx, C.byref(s), C.byref(m), C.byref(p)), 'ccsp_log_device_ptrs')

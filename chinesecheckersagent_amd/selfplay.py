@@ -3,7 +3,8 @@ GPU-resident engine.
 
     selfplay(model1, model2=None, randomised=False)                  selfplay.py:11-80
     generate_self_play(worker_id, model_path, num_self_play, ...)    train.py:27-67
-    selfplay_batch(...)                                              many games as one batch (new)
+    generate_self_play_in_parallel(model_path, num_self_play, num_workers, model2_path=None)    train.py:71-105, one rank per GPU
+    selfplay_batch(...) / generate_train_data(...)                   many games in <= 4096 restarting slots (SelfPlayRun)
 
 `model` is anything with the batched evaluator interface of model.ResidualCNN
 (`evaluate_batch(x[G,7,7,7] f32 cuda) -> (p f64 [G,294], v f32 [G])`); the reference's duck-typed
@@ -52,6 +53,17 @@ def _batched(model):
     return model if hasattr(model, 'evaluate_batch') else _PredictAdapter(model)
 
 
+def _strict():
+    """CCSP_STRICT=1 (bench.py sets it): a performance path that cannot be taken is an error, not a silent fallback"""
+    import os
+    return os.environ.get('CCSP_STRICT') == '1'
+
+
+def _warn(msg):
+    import sys
+    sys.stderr.write('chinesecheckersagent_amd: ' + msg + '\n')
+
+
 class BatchSelfPlay(object):
     """n_slots concurrent games through the stepped path (external evaluator)."""
 
@@ -84,48 +96,54 @@ class BatchSelfPlay(object):
             v = self.torch.where(root_is_p2, v2, v)
         return p.contiguous(), v.contiguous()
 
+    def _capture(self, root_is_p2, p, v):
+        """several simulation steps -> one hipGraph (one hipGraphLaunch, and its host / front-end cost, per `unroll` steps).
+        A failed capture is reported (and is an error under CCSP_STRICT=1); the ply then runs on plain launches."""
+        torch, e = self.torch, self.eng
+        selected = False
+        keep = []
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                     # warm-up on a side stream (allocator)
+                for _ in range(2):
+                    self._evaluate(root_is_p2)
+            torch.cuda.current_stream().wait_stream(s)
+            self._unroll = max(k for k in (25, 20, 16, 10, 8, 5, 4, 2, 1) if self.sims % k == 0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):                      # capture only: nothing executes here
+                e.select(self.planes)
+                selected = True
+                for i in range(self._unroll):              # [evaluate -> expand/backup + the next selection] in one tree launch
+                    gp, gv = self._evaluate(root_is_p2)
+                    if i + 1 < self._unroll:
+                        e.expand_backup_select(gp, gv, self.planes)
+                    else:
+                        e.expand_backup(gp, gv)
+                        selected = False
+                    keep.append((gp, gv))
+            self._graph = g
+            self._graph_out = keep                         # keep the captured outputs alive
+        except Exception as ex:
+            self.use_graph = False
+            self._graph = None
+            if selected:                                   # close the half-captured step on the host side
+                e.expand_backup(p, v)                      # (device side: no pending leaf -> no-op)
+            if _strict():
+                raise
+            _warn('hipGraph capture of the simulation steps failed (%r): this batch runs on plain launches' % (ex,))
+
     def play_ply(self):
         """one ply of every running slot: random opening move, or root expansion + sims x
         (select -> net -> expand/backup) + pi + move"""
         e = self.eng
-        torch = self.torch
         e.ply_begin(self.planes)
         self._root_is_p2.copy_(self.planes[:, 0, 0, 6] == 1)
         root_is_p2 = self._root_is_p2
         p, v = self._evaluate(root_is_p2)
         e.root_expand(p, v)
         if self.use_graph and self._graph is None:
-            try:
-                s = torch.cuda.Stream()
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):                     # warm-up on a side stream (allocator, MIOpen find)
-                    for _ in range(2):
-                        self._evaluate(root_is_p2)
-                torch.cuda.current_stream().wait_stream(s)
-                # several simulation steps per graph: one hipGraphLaunch (and its host/front-end cost) per
-                # `unroll` steps instead of per step
-                self._unroll = max(k for k in (25, 20, 16, 10, 8, 5, 4, 2, 1) if self.sims % k == 0)
-                g = torch.cuda.CUDAGraph()
-                selected = False
-                keep = []
-                with torch.cuda.graph(g):                      # capture only: nothing executes here
-                    e.select(self.planes)
-                    selected = True
-                    for i in range(self._unroll):              # [evaluate -> expand/backup + the next selection] in one tree launch
-                        gp, gv = self._evaluate(root_is_p2)
-                        if i + 1 < self._unroll:
-                            e.expand_backup_select(gp, gv, self.planes)
-                        else:
-                            e.expand_backup(gp, gv)
-                            selected = False
-                        keep.append((gp, gv))
-                self._graph = g
-                self._graph_out = keep                         # keep the captured outputs alive
-            except Exception:
-                self.use_graph = False
-                self._graph = None
-                if selected:                                   # close the half-captured step on the host side
-                    e.expand_backup(p, v)                      # (device side: no pending leaf -> no-op)
+            self._capture(root_is_p2, p, v)
         if self._graph is not None:
             for _ in range(self.sims // self._unroll):
                 self._graph.replay()
@@ -142,53 +160,43 @@ class BatchSelfPlay(object):
     def run_to_completion(self, max_plies=2048):
         for i in range(max_plies):
             self.play_ply()
-            if i % 8 == 7 and (self.eng.slots()['status'] != _lib.ST_RUNNING).all():
+            if i % 8 == 7 and (self.eng.slots()['status'] == _lib.ST_RUNNING).sum() == 0:
                 break
         return self.collect()
 
+    def harvest(self):
+        """the rows logged since the last harvest and the result table as it stands, as ONE part:
+        [(state, meta, pi, results, first_game, game_stride)]; the device log is empty again afterwards"""
+        e = self.eng
+        st, meta, pi = e.log()
+        e.log_clear()
+        return [(st, meta, pi, e.results(), e.first_game, e.game_stride)]
+
     def _check_log_complete(self):
-        """a full sample log drops rows (the engine ends such games with status ERROR and counts an error): games
-        with missing plies must never reach the training data, so collecting from such a run raises"""
+        """a full sample log drops rows (the engine ends such a game with status ERROR, counts an error and leaves the slot
+        out of play): games with missing plies never reach the training data"""
         c = self.eng.counters()
         if c['errors']:
             raise _lib.CcspError('%d engine errors (sample log full after %d of %d rows, or a game ended in ERROR): '
-                                 'raise log_capacity' % (c['errors'], self.eng.log_size(), self.eng.log_capacity))
+                                 'raise log_capacity, or harvest() more often' % (c['errors'], self.eng.log_size(), self.eng.log_capacity))
 
-    def collect(self):
+    def collect(self, allow_errors=False):
         """per finished game, in game-id order: (play_history, p1_reward) or (None, None) -- the
-        return value of selfplay() (selfplay.py:45-47, 72-80)"""
+        return value of selfplay() (selfplay.py:45-47, 72-80).  A game that ended in ERROR raises, or with
+        allow_errors=True is handed back as ('error', status) beside the whole games."""
         e = self.eng
-        self._check_log_complete()
+        if not allow_errors:
+            self._check_log_complete()
         st, meta, pi = e.log()
-        res = e.results()
-        order = np.lexsort((meta['ply'], meta['game']))
-        by_game = {}
-        for r in order:
-            by_game.setdefault(int(meta['game'][r]), []).append(r)
-        out = []
-        for k in range(len(res)):
-            game = e.first_game + k * e.game_stride
-            status = int(res['status'][k])
-            if status in (_lib.ST_WON_P1, _lib.ST_WON_P2):
-                rows = by_game.get(game, [])
-                if self.randomised:
-                    rows = rows[3:]                         # selfplay.py:76-78
-                hist = [(BoardView(st[r]), pi[r].copy()) for r in rows]
-                out.append((hist, int(res['reward'][k])))
-            elif status in (_lib.ST_DISCARD_REPETITION, _lib.ST_DISCARD_NO_PROGRESS):
-                out.append((None, None))
-            elif status == _lib.ST_ERROR:
-                raise _lib.CcspError('game %d ended in ERROR status' % game)
-            else:
-                out.append(('unfinished', status))
-        return out
+        return _games_from_rows(st, meta, pi, e.results(), e.first_game, e.game_stride, self.randomised, allow_errors)
 
-    def collect_train_data(self):
+    def collect_train_data(self, allow_errors=False):
         """utils.convert_to_train_data(self.collect()) as arrays, without building a Python object per position
         (utils.log_to_train_data): (board_x [N,7,7,7] f64, pi_y [N,294] f64, v_y [N] int64) of the games won so far"""
         from . import utils
         e = self.eng
-        self._check_log_complete()
+        if not allow_errors:
+            self._check_log_complete()
         st, meta, pi = e.log()
         return utils.log_to_train_data(st, meta, pi, e.results(), first_game=e.first_game, game_stride=e.game_stride,
                                        randomised=self.randomised)
@@ -197,27 +205,57 @@ class BatchSelfPlay(object):
         self.eng.close()
 
 
+def _games_from_rows(st, meta, pi, res, first_game, game_stride, randomised, allow_errors=False):
+    """sample rows + result table -> [(play_history, p1_reward) | (None, None) | ('unfinished' | 'error', status)] by game index"""
+    order = np.lexsort((meta['ply'], meta['game']))
+    by_game = {}
+    for r in order:
+        by_game.setdefault(int(meta['game'][r]), []).append(r)
+    out = []
+    for k in range(len(res)):
+        game = first_game + k * game_stride
+        status = int(res['status'][k])
+        if status in (_lib.ST_WON_P1, _lib.ST_WON_P2):
+            rows = by_game.get(game, [])
+            if randomised:
+                rows = rows[3:]                         # selfplay.py:76-78
+            hist = [(BoardView(st[r]), pi[r].copy()) for r in rows]
+            out.append((hist, int(res['reward'][k])))
+        elif status in (_lib.ST_DISCARD_REPETITION, _lib.ST_DISCARD_NO_PROGRESS):
+            out.append((None, None))
+        elif status == _lib.ST_ERROR:
+            if not allow_errors:
+                raise _lib.CcspError('game %d ended in ERROR status' % game)
+            out.append(('error', status))
+        else:
+            out.append(('unfinished', status))
+    return out
+
+
 class PipelinedSelfPlay(object):
     """The same batch as `n_parts` BatchSelfPlay halves on their own HIP streams (game ids interleaved), so that the
     select / expand-backup kernels and launch gaps of one half run under the evaluator kernel of the other: the
     evaluator fills the GPU with one workgroup per CU at 2048 positions, the tree kernels need almost nothing.
     4096 games x 400 simulations with good_model.h5: 12.5 -> 13.4 M node-expansions/s with two parts (four are slower).
-    Same interface as BatchSelfPlay (play_ply / run_to_completion / collect / close)."""
+    Same interface as BatchSelfPlay (play_ply / run_to_completion / harvest / collect / close)."""
 
     def __init__(self, model1, model2=None, n_slots=2, n_parts=2, first_game=0, game_stride=1, max_games=None, log_capacity=None,
                  auto_restart=False, **kw):
         import torch
         max_games = n_slots if max_games is None else max_games
-        # part i plays ids first_game + (i + k n_parts) game_stride: with restarts every part draws from its own id budget
-        assert n_slots % n_parts == 0 and max_games % n_parts == 0 and (auto_restart or max_games == n_slots)
+        # part i plays ids first_game + (i + k n_parts) game_stride, k < ceil((max_games - i) / n_parts): with restarts every part
+        # draws from its own id budget
+        assert n_slots % n_parts == 0 and (auto_restart or max_games == n_slots)
         self.torch = torch
         self.n_parts, self.n_slots = n_parts, n_slots
         per = n_slots // n_parts
         self.parts = [BatchSelfPlay(model1, model2, n_slots=per, first_game=first_game + i * game_stride,
-                                    game_stride=game_stride * n_parts, max_games=max_games // n_parts, auto_restart=auto_restart,
-                                    log_capacity=None if log_capacity is None else log_capacity // n_parts, **kw)
+                                    game_stride=game_stride * n_parts, max_games=max(1, (max_games - i + n_parts - 1) // n_parts),
+                                    auto_restart=auto_restart,
+                                    log_capacity=None if log_capacity is None else (log_capacity + n_parts - 1) // n_parts, **kw)
                       for i in range(n_parts)]
         self.streams = [torch.cuda.Stream() for _ in range(n_parts)]
+        self.max_games = max_games
 
     def play_ply(self):
         cur = self.torch.cuda.current_stream()
@@ -245,13 +283,17 @@ class PipelinedSelfPlay(object):
                 break
         return self.collect()
 
-    def collect(self):
-        outs = [b.collect() for b in self.parts]
-        return [outs[j % self.n_parts][j // self.n_parts] for j in range(sum(len(o) for o in outs))]
+    def harvest(self):
+        return [h for b in self.parts for h in b.harvest()]
 
-    def collect_train_data(self):
+    def collect(self, allow_errors=False):
+        outs = [b.collect(allow_errors) for b in self.parts]
+        n = min(self.max_games, sum(len(o) for o in outs))
+        return [outs[j % self.n_parts][j // self.n_parts] for j in range(n)]
+
+    def collect_train_data(self, allow_errors=False):
         """the parts' samples, concatenated (training order is shuffled anyway)"""
-        outs = [b.collect_train_data() for b in self.parts]
+        outs = [b.collect_train_data(allow_errors) for b in self.parts]
         return tuple(np.concatenate([o[i] for o in outs]) for i in range(3))
 
     def close(self):
@@ -259,23 +301,258 @@ class PipelinedSelfPlay(object):
             b.close()
 
 
+class GameStore(object):
+    """Host side of a harvested run: the sample rows of the games still being played, the result of every game that
+    has ended (by GLOBAL game index j: id = first_game + j * game_stride) and what became of the finished games' rows --
+    kept as records (the object path: selfplay()'s play_history) and / or handed on as (board_x, pi_y, v_y) chunks."""
+
+    def __init__(self, n_games, first_game, game_stride, randomised, keep_records=True):
+        self.n_games, self.first_game, self.game_stride = int(n_games), int(first_game), int(game_stride)
+        self.randomised = bool(randomised)
+        self.results = np.zeros(self.n_games, dtype=_lib.RESULT_DTYPE)
+        self.results['status'] = 0xFF                                    # not finished yet (ccsp_reset's fill)
+        self.keep_records = keep_records
+        self._pending = None                                             # rows of games without a result yet
+        self._records = []                                               # rows of finished games (object path)
+        self.rows_seen = 0
+
+    def add(self, parts):
+        """parts = the harvest() of a batch: rows are appended to the pending set, result tables merged by global index"""
+        new = []
+        for st, meta, pi, res, first, stride in parts:
+            j0 = (first - self.first_game) // self.game_stride              # part-local index k <-> global index j0 + k * step
+            step = stride // self.game_stride
+            j = j0 + np.arange(len(res)) * step
+            ok = j < self.n_games
+            self.results[j[ok]] = res[ok]
+            if len(meta):
+                new.append((st, meta, pi))
+                self.rows_seen += len(meta)
+        if self._pending is not None:
+            new.insert(0, self._pending)
+        if new:
+            self._pending = tuple(np.concatenate([x[i] for x in new]) for i in range(3)) if len(new) > 1 else new[0]
+
+    def finished(self):
+        return bool((self.results['status'] != 0xFF).all())
+
+    def n_finished(self):
+        return int((self.results['status'] != 0xFF).sum())
+
+    def take_finished(self):
+        """(board_x, pi_y, v_y) of the games that have ended since the last call (won games only, utils.convert_to_train_data's
+        rows and labels); their rows leave the pending set.  None if nothing ended."""
+        from . import utils
+        if self._pending is None:
+            return None
+        st, meta, pi = self._pending
+        j = (np.asarray(meta['game'], dtype=np.int64) - self.first_game) // self.game_stride
+        done = self.results['status'][j] != 0xFF
+        if not done.any():
+            return None
+        d = (st[done], meta[done], pi[done])
+        self._pending = (st[~done], meta[~done], pi[~done]) if (~done).any() else None
+        if self.keep_records:
+            self._records.append(d)
+        return utils.log_to_train_data(d[0], d[1], d[2], self.results, first_game=self.first_game, game_stride=self.game_stride,
+                                       randomised=self.randomised, return_games=True)
+
+    def games(self, allow_errors=False):
+        """[(play_history, p1_reward) | (None, None)] in game-id order (the object path)"""
+        assert self.keep_records
+        self.take_finished()
+        rows = list(self._records) + ([self._pending] if self._pending is not None else [])
+        if rows:
+            st, meta, pi = (np.concatenate([x[i] for x in rows]) for i in range(3))
+        else:
+            st, meta, pi = (np.zeros(0, dtype=_lib.STATE_DTYPE), np.zeros(0, dtype=_lib.META_DTYPE), np.zeros((0, NUM_ACTIONS)))
+        return _games_from_rows(st, meta, pi, self.results, self.first_game, self.game_stride, self.randomised, allow_errors)
+
+
+MAX_SLOTS = 4096          # concurrent games per GPU (BASELINE.json); more games than this restart in the slots that come free
+HARVEST_EVERY = 16        # plies between two harvests of the sample log
+
+
+class SelfPlayRun(object):
+    """`n_games` self-play games on one GPU the way bench.py measures them: min(n_games, max_slots) game slots, a slot that
+    finishes its game starts the slot's next one by itself (ids first_game + j * game_stride, j < n_games; a game's record is
+    a function of its id alone), two half-batches on their own streams when the batch is large, the sample log harvested
+    every `harvest_every` plies -- so device memory is n_slots tree pools + n_slots x (harvest_every + 1) log rows whatever
+    n_games is, and the log cannot overflow.
+    `sink(board_x, pi_y, v_y)` (optional) receives the training rows of the games that ended, harvest by harvest, from a
+    worker thread that converts while the GPU plays on."""
+
+    def __init__(self, model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False, first_game=0,
+                 game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY, use_graph=True, keep_records=True,
+                 sink=None, n_parts=None):
+        n_games = int(n_games)
+        n_slots = max(1, min(n_games, int(max_slots)))
+        if n_parts is None:
+            n_parts = 2 if (n_slots >= 2048 and hasattr(_batched(model1), 'model')) else 1
+        n_slots -= n_slots % n_parts
+        self.n_games, self.n_slots, self.harvest_every = n_games, n_slots, int(harvest_every)
+        kw = dict(sims=sims, seed=seed, first_game=first_game, game_stride=game_stride, max_games=n_games, randomised=randomised,
+                  auto_restart=True, device=device, use_graph=use_graph)
+        cap = n_slots * (self.harvest_every + 1)
+        if n_parts > 1:
+            self.b = PipelinedSelfPlay(model1, model2, n_slots=n_slots, n_parts=n_parts, log_capacity=cap, **kw)
+            self.counters = self.b.counters
+        else:
+            self.b = BatchSelfPlay(model1, model2, n_slots=n_slots, log_capacity=cap, **kw)
+            self.counters = self.b.eng.counters
+        self.store = GameStore(n_games, first_game, game_stride, randomised, keep_records=keep_records)
+        self.sink = sink
+        self.plies = 0
+        self._since = 0
+        self._worker = self._queue = None
+        self._worker_error = []
+        if sink is not None:
+            import queue
+            import threading
+            self._queue = queue.Queue(maxsize=4)
+            self._worker = threading.Thread(target=self._drain, daemon=True)
+            self._worker.start()
+
+    # the worker thread: merge a harvest into the store, convert the finished games' rows, hand them to the sink
+    def _drain(self):
+        while True:
+            parts = self._queue.get()
+            if parts is None:
+                return
+            try:
+                self._absorb(parts)
+            except Exception as ex:                      # reported by the main thread at the next harvest / at finish()
+                self._worker_error.append(ex)
+
+    def _absorb(self, parts):
+        self.store.add(parts)
+        if self.sink is not None:
+            chunk = self.store.take_finished()
+            if chunk is not None and len(chunk[2]):
+                self.sink(*chunk)
+
+    def play_ply(self):
+        self.b.play_ply()
+        self.plies += 1
+        self._since += 1
+        if self._since >= self.harvest_every:
+            self.harvest()
+
+    def harvest(self):
+        parts = self.b.harvest()                          # synchronises, copies the rows out, empties the device log
+        self._since = 0
+        if self._worker_error:
+            raise self._worker_error[0]
+        if self._queue is not None:
+            self._queue.put(parts)
+        else:
+            self._absorb(parts)
+
+    def flush(self):
+        """harvest what is left and wait for the worker: the store (and the sink) then hold everything played so far"""
+        self.harvest()
+        if self._queue is not None:
+            self._queue.put(None)
+            self._worker.join()
+            self._worker = self._queue = None
+            if self._worker_error:
+                raise self._worker_error[0]
+
+    def run(self, max_plies=None):
+        """play until every game has a result"""
+        limit = max_plies if max_plies is not None else 1100 * ((self.n_games + self.n_slots - 1) // self.n_slots) + 64
+        while self.plies < limit:
+            for _ in range(self.harvest_every):
+                self.b.play_ply()
+            self.plies += self.harvest_every
+            self.harvest()
+            if self._queue is None and self.store.finished():
+                break
+            if self._queue is not None and not self.b_running():
+                break
+        self.flush()
+        return self
+
+    def b_running(self):
+        if hasattr(self.b, 'running'):
+            return self.b.running()
+        return bool((self.b.eng.slots()['status'] == _lib.ST_RUNNING).any())
+
+    def games(self, allow_errors=False):
+        return self.store.games(allow_errors)
+
+    def errors(self):
+        return self.counters()['errors']
+
+    def close(self):
+        if self._queue is not None:
+            self._queue.put(None)
+            self._worker.join()
+            self._worker = self._queue = None
+        self.b.close()
+
+
+class TrainDataSink(object):
+    """collects the (board_x, pi_y, v_y, game id per row) chunks of a SelfPlayRun; arrays() / save() give
+    utils.convert_to_train_data's output"""
+
+    def __init__(self):
+        self.chunks = []
+        self.rows = 0
+
+    def __call__(self, board_x, pi_y, v_y, games):
+        self.chunks.append((board_x, pi_y, v_y, games))
+        self.rows += len(v_y)
+
+    def arrays(self, canonical=True, with_games=False):
+        """canonical: games in id order (what convert_to_train_data(selfplay_batch(...)) gives) instead of the order they ended in"""
+        if not self.chunks:
+            out = (np.zeros((0, 7, 7, 7)), np.zeros((0, NUM_ACTIONS)), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+        else:
+            out = tuple(np.concatenate([c[i] for c in self.chunks]) for i in range(4))
+            if canonical:
+                o = np.argsort(out[3], kind='stable')
+                out = tuple(x[o] for x in out)
+        return out if with_games else out[:3]
+
+    def save(self, version, directory=None):
+        """utils.save_train_data (utils.py:48-56) of everything collected; the datasets are streamed chunk by chunk"""
+        from . import utils
+        from .config import SAVE_TRAIN_DATA_DIR
+        bx, py, vy = self.arrays()
+        return utils.save_train_data(bx, py, vy, version, SAVE_TRAIN_DATA_DIR if directory is None else directory)
+
+
 def selfplay_batch(model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False,
-                   first_game=0, game_stride=1, device=0):
-    """n_games games as one batch; returns [(play_history, p1_reward) | (None, None)] in game-id order"""
-    if n_games >= 2048 and n_games % 2 == 0 and hasattr(_batched(model1), 'model'):
-        b = PipelinedSelfPlay(model1, model2, n_slots=n_games, n_parts=2, sims=sims, seed=seed, first_game=first_game,
-                              game_stride=game_stride, randomised=randomised, device=device, log_capacity=n_games * 512)
-        try:
-            return b.run_to_completion()
-        finally:
-            b.close()
-    b = BatchSelfPlay(model1, model2, n_slots=n_games, sims=sims, seed=seed, first_game=first_game,
-                      game_stride=game_stride, max_games=n_games, randomised=randomised, device=device,
-                      log_capacity=n_games * 512)
+                   first_game=0, game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY):
+    """n_games games; returns [(play_history, p1_reward) | (None, None)] in game-id order.  The games run in
+    min(n_games, max_slots) slots with restarts (SelfPlayRun): the steady-state mode bench.py measures."""
+    run = SelfPlayRun(model1, model2, n_games=n_games, sims=sims, seed=seed, randomised=randomised, first_game=first_game,
+                      game_stride=game_stride, device=device, max_slots=max_slots, harvest_every=harvest_every)
     try:
-        return b.run_to_completion()
+        return run.run().games()
     finally:
-        b.close()
+        run.close()
+
+
+def generate_train_data(model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False, first_game=0,
+                        game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY):
+    """utils.convert_to_train_data(selfplay_batch(...)) without a Python object per position: the finished games' rows are
+    converted harvest by harvest while the GPU plays on.  -> (board_x [N,7,7,7] f64, pi_y [N,294] f64, v_y [N] int64,
+    summary dict); the same rows in the same order as utils.convert_to_train_data(generate_self_play's list)."""
+    sink = TrainDataSink()
+    run = SelfPlayRun(model1, model2, n_games=n_games, sims=sims, seed=seed, randomised=randomised, first_game=first_game,
+                      game_stride=game_stride, device=device, max_slots=max_slots, harvest_every=harvest_every,
+                      keep_records=False, sink=sink)
+    try:
+        run.run()
+        st = run.store.results['status']
+        summary = dict(games=n_games, won=int(((st == _lib.ST_WON_P1) | (st == _lib.ST_WON_P2)).sum()),
+                       discarded=int(((st == _lib.ST_DISCARD_REPETITION) | (st == _lib.ST_DISCARD_NO_PROGRESS)).sum()),
+                       errors=int((st == _lib.ST_ERROR).sum()), plies=run.plies, counters=run.counters())
+        return sink.arrays() + (summary,)
+    finally:
+        run.close()
 
 
 def selfplay(model1, model2=None, randomised=False, sims=MCTS_SIMULATIONS, seed=None, game_id=None):
@@ -286,22 +563,95 @@ def selfplay(model1, model2=None, randomised=False, sims=MCTS_SIMULATIONS, seed=
     return selfplay_batch(model1, model2, n_games=1, sims=sims, seed=seed, randomised=randomised, first_game=game_id)[0]
 
 
-def generate_self_play(worker_id, model_path, num_self_play, model2_path=None, sims=MCTS_SIMULATIONS, seed=None):
-    """train.py:27-67: load the model(s) and return [(play_history, p1_reward)] of the games that were
-    not discarded.  The games are played as ONE batch on this worker's GPU; worker w of W plays game ids
-    w-1, w-1+W, ... when the caller passes seeds/ids accordingly (see parallel use in INTEGRATION.md)."""
+def _load_models(model_path, model2_path=None, device=None):
     from .model import ResidualCNN
-    model = ResidualCNN()
+    model = ResidualCNN(device=device)
     model2 = None
     if model_path is not None:
         model.load_weights(model_path)
         if model2_path is not None:
-            model2 = ResidualCNN()
+            model2 = ResidualCNN(device=device)
             model2.load_weights(model2_path)
-    first = _next_game[0]
-    _next_game[0] += num_self_play
-    games = selfplay_batch(model, model2, n_games=num_self_play, sims=sims, seed=seed, first_game=first)
-    return [(h, r) for h, r in games if h is not None and r is not None and h != 'unfinished']
+    return model, model2
+
+
+def generate_self_play(worker_id, model_path, num_self_play, model2_path=None, sims=MCTS_SIMULATIONS, seed=None,
+                       first_game=None, game_stride=1, device=0):
+    """train.py:27-67: load the model(s) and return [(play_history, p1_reward)] of the games that were
+    not discarded.  The games are played on this worker's GPU in up to MAX_SLOTS concurrent slots; worker w of W
+    plays game ids first_game + k * game_stride (generate_self_play_in_parallel passes w and W)."""
+    model, model2 = _load_models(model_path, model2_path, device='cuda:%d' % device)
+    if first_game is None:
+        first_game = _next_game[0]
+        _next_game[0] += num_self_play * game_stride
+    games = selfplay_batch(model, model2, n_games=num_self_play, sims=sims, seed=seed, first_game=first_game,
+                           game_stride=game_stride, device=device)
+    return [(h, r) for h, r in games if h is not None and r is not None and not isinstance(h, str)]
+
+
+def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model2_path=None, sims=MCTS_SIMULATIONS, seed=None,
+                                   first_game=None, randomised=False, devices=None, as_arrays=False, out_dir=None, max_slots=MAX_SLOTS,
+                                   return_summary=False):
+    """train.generate_self_play_in_parallel (train.py:71-105) with GPUs for workers: `num_workers` rank processes, one per
+    MI355X (devices[r], default r), are started from THIS process -- which never touches the GPU -- and play the ids
+    first_game + j, j < num_self_play, sharded j mod num_workers; their counters and visit histograms meet in one RCCL
+    all-reduce.  Returns the reference's list [(play_history, p1_reward)] of the games that were not discarded, in game-id
+    order (as_arrays=True: utils.convert_to_train_data of that list as (board_x, pi_y, v_y) arrays, no object per position);
+    with return_summary=True also the all-reduced summary {'counters': ..., 'visit_histogram': ...}."""
+    import json
+    import os
+    import sys
+    import tempfile
+    from . import launch, utils
+    if first_game is None:
+        first_game = _next_game[0]
+        _next_game[0] += num_self_play
+    seed = _default_seed[0] if seed is None else seed
+    tmp = None
+    if out_dir is None:
+        tmp = tempfile.TemporaryDirectory(prefix='ccsp-selfplay-')
+        out_dir = tmp.name
+    try:
+        argv = [sys.executable, '-m', 'chinesecheckersagent_amd.worker', 'selfplay', '--games', str(num_self_play), '--sims', str(sims),
+                '--seed', str(seed), '--first-game', str(first_game), '--max-slots', str(max_slots), '--out', out_dir]
+        if model_path is not None:
+            argv += ['--model', model_path]
+        if model2_path is not None:
+            argv += ['--model2', model2_path]
+        if randomised:
+            argv += ['--randomised']
+        extra = {'PYTHONPATH': os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
+                                               ([os.environ['PYTHONPATH']] if os.environ.get('PYTHONPATH') else []))}
+        if devices is not None and len(set(devices)) < len(devices):
+            extra['CCSP_ONE_DEVICE'] = '1'                 # several ranks on one device: gloo carries the summary
+        rc = launch.run_ranks(argv, num_workers, devices=devices, extra_env=extra)
+        if rc:
+            raise _lib.CcspError('generate_self_play_in_parallel: a rank process failed (exit code %d)' % rc)
+        results = np.zeros(num_self_play, dtype=_lib.RESULT_DTYPE)
+        results['status'] = 0xFF
+        rows = []
+        for r in range(num_workers):
+            path = os.path.join(out_dir, 'selfplay-rank%d.npz' % r)
+            if not os.path.exists(path):                   # a rank with no game to play
+                continue
+            z = np.load(path)
+            res = z['results']
+            results[r + np.arange(len(res)) * num_workers] = res
+            rows.append((z['state'], z['meta'], z['pi']))
+        st, meta, pi = (np.concatenate([x[i] for x in rows]) for i in range(3)) if rows else \
+            (np.zeros(0, dtype=_lib.STATE_DTYPE), np.zeros(0, dtype=_lib.META_DTYPE), np.zeros((0, NUM_ACTIONS)))
+        if as_arrays:
+            out = utils.log_to_train_data(st, meta, pi, results, first_game=first_game, game_stride=1, randomised=randomised)
+        else:
+            games = _games_from_rows(st, meta, pi, results, first_game, 1, randomised)
+            out = [(h, r) for h, r in games if h is not None and r is not None and not isinstance(h, str)]
+        if return_summary:
+            with open(os.path.join(out_dir, 'summary.json')) as f:
+                return out, json.load(f)
+        return out
+    finally:
+        if tmp is not None:
+            tmp.cleanup()
 
 
 def bench_net_plies(n_slots, sims, plies=2, weights=None, precision='fp32'):

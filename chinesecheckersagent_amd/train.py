@@ -11,7 +11,9 @@ with the model and losses of model.py:58-87 / loss.py:3-4 on PyTorch(-ROCm):
 PARITY UNPINNED: Keras/TensorFlow are not installed and the reference holds no training vectors, so this
 follows the documented Keras 2.1.6 semantics; its step is checked against a hand-derived NumPy float64 restatement of those
 semantics (oracle/train_oracle.py, tests/test_train.py), not against Keras itself.  Multi-GPU: one
-process per GPU, DistributedDataParallel (RCCL) averages the 999,408-byte gradient each step.
+process per GPU; every rank takes its share of each GLOBAL batch of 32, BatchNormalization statistics are all-reduced over the
+ranks (the step is the one a single GPU takes on the whole batch, moving statistics included) and DistributedDataParallel
+(RCCL) averages the 999,408-byte gradient each step.
 Weights are read from and written to the reference's own `versionNNNN-weights.h5` layout (h5lite).
 """
 import os
@@ -55,8 +57,34 @@ def _build(filters=NUM_FILTERS):
     import torch
     nn = torch.nn
 
+    class BatchNorm(nn.BatchNorm2d):
+        """nn.BatchNorm2d whose TRAINING statistics are taken over the rows of every rank (sync = the process group is
+        initialised and Trainer(ddp=True) switched it on): mean and biased variance of the global batch through two
+        differentiable all-reduces, the moving variance from the unbiased global one -- exactly what ONE process computes
+        on the whole batch, so N ranks with 32 / N rows each take the single-GPU step (with plain per-rank BatchNorm the
+        statistics would come from 4 rows at N = 8).  Works over RCCL and over gloo (CPU tests)."""
+        sync = False
+
+        def forward(self, x):
+            if not (self.training and self.sync):
+                return super().forward(x)
+            import torch.distributed as dist
+            import torch.distributed.nn.functional as dfn
+            cnt = torch.tensor([float(x.shape[0] * x.shape[2] * x.shape[3])], dtype=x.dtype, device=x.device)
+            dist.all_reduce(cnt)
+            mean = dfn.all_reduce(x.sum(dim=(0, 2, 3))) / cnt
+            xc = x - mean[None, :, None, None]
+            var = dfn.all_reduce((xc * xc).sum(dim=(0, 2, 3))) / cnt
+            with torch.no_grad():
+                m = self.momentum
+                self.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
+                self.running_var.mul_(1 - m).add_(var.detach() * (cnt / (cnt - 1)), alpha=m)
+                self.num_batches_tracked += 1
+            y = xc * torch.rsqrt(var + self.eps)[None, :, None, None]
+            return y * self.weight[None, :, None, None] + self.bias[None, :, None, None]
+
     def bn(c):                                   # Keras momentum 0.99 <-> torch momentum 0.01
-        return nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
+        return BatchNorm(c, eps=1e-3, momentum=0.01)
 
     class TrainNet(nn.Module):
         """the reference graph with explicit BatchNorm layers (the inference module of model.py folds them)"""
@@ -114,7 +142,10 @@ class Trainer(object):
         self.net = _build().to(self.device)
         self.ddp = None
         if ddp:
-            self.ddp = torch.nn.parallel.DistributedDataParallel(self.net, device_ids=[self.device.index] if self.device.type == 'cuda' else None)
+            for b in self.net.bns.values():
+                b.sync = True                        # global-batch statistics: identical on every rank, nothing to broadcast
+            self.ddp = torch.nn.parallel.DistributedDataParallel(self.net, device_ids=[self.device.index] if self.device.type == 'cuda' else None,
+                                                                 broadcast_buffers=False)
         self.opt = torch.optim.SGD(self.net.parameters(), lr=LEARNING_RATE, momentum=0.9, nesterov=True)
 
     # ---- weights in the reference's file layout ------------------------------------------------------------
@@ -156,12 +187,13 @@ class Trainer(object):
 
     def save_weights(self, save_dir, prefix, version):
         """Model.save_weights (model.py:33-37): '{dir}/{prefix}{version:0>4}-weights.h5' in Keras' own layout"""
-        if not os.path.exists(save_dir):
-            os.makedirs(save_dir)
+        os.makedirs(save_dir, exist_ok=True)
         st = self.state_as_keras()
         layers = [(ln, [(wn, st[wn].astype(np.float32)) for wn in wns]) for ln, wns in keras_layer_names()]
         path = '{}/{}{:0>4}-weights.h5'.format(save_dir, prefix, version)
-        write_keras_weights(path, layers)
+        tmp = '%s.tmp%d' % (path, os.getpid())
+        write_keras_weights(tmp, layers)
+        os.replace(tmp, path)                         # readers see the old file or the whole new one
         return path
 
     # ---- loss and step -----------------------------------------------------------------------------------------
@@ -172,11 +204,17 @@ class Trainer(object):
         reg = sum((k ** 2).sum() for k in self.net.kernels()) * REG_CONST                  # l2 on every kernel
         return policy + value + reg, policy, value, reg
 
-    def step(self, x, pi, z):
+    def step(self, x, pi, z, global_rows=None):
+        """one optimisation step.  Under ddp a rank passes ITS rows of the global batch and the batch's size: its data terms
+        are weighted len(x) * world / global_rows, so that DistributedDataParallel's mean over ranks is the mean over the
+        global batch whatever the shares (regulariser: the same on every rank)."""
         self.net.train()
         model = self.ddp if self.ddp is not None else self.net
         logits, v = model(x)
         total, policy, value, reg = self.loss(logits, v, pi, z)
+        if self.ddp is not None and global_rows is not None:
+            import torch.distributed as dist
+            total = (policy + value) * (len(x) * dist.get_world_size() / float(global_rows)) + reg
         self.opt.zero_grad(set_to_none=True)
         total.backward()
         self.opt.step()
@@ -201,15 +239,18 @@ class Trainer(object):
             for i in range(0, split, batch_size):
                 idx = perm[i:i + batch_size]
                 if self.ddp is not None:
-                    # every rank draws the SAME permutation (same seed) and takes its own equal share of each global batch:
-                    # the gradient DistributedDataParallel averages is then the mean over the global batch, not N copies
-                    # of the same work; what does not divide by the world size is dropped from that batch
+                    # every rank draws the SAME permutation (same seed) and takes its own share of each global batch (rows
+                    # rank, rank + world, ...: shares differ by at most one row and step() weights them, so the averaged
+                    # gradient is the global batch's); a batch with fewer rows than ranks is skipped on every rank alike
                     import torch.distributed as dist
                     world, rank = dist.get_world_size(), dist.get_rank()
-                    idx = idx[:len(idx) // world * world][rank::world]
-                    if len(idx) == 0:
+                    n_global = len(idx)
+                    if n_global < world:
                         continue
-                l = self.step(xt[idx], pt[idx], zt[idx])[0]
+                    idx = idx[rank::world]
+                    l = self.step(xt[idx], pt[idx], zt[idx], global_rows=n_global)[0]
+                else:
+                    l = self.step(xt[idx], pt[idx], zt[idx])[0]
                 tot += l * len(idx); cnt += len(idx)
             val = None
             if len(xv):
@@ -224,7 +265,9 @@ def train(model_path, board_x, pi_y, v_y, data_retention, version, save_dir=SAVE
     """train.train (train.py:109-146): load weights, keep a random `data_retention` fraction of the samples
     (train.py:134-137), fit, save 'saved-weights/version{version:0>4}-weights.h5'.  Returns the path.
     ddp=True (one process per GPU, torch.distributed initialised by the caller): every rank calls this with the SAME
-    arrays and seed; fit() gives each rank its share of every batch, the replicas stay identical, rank 0's file is the result."""
+    arrays and seed; fit() gives each rank its share of every global batch, BatchNormalization statistics are global, so the
+    replicas stay identical -- moving statistics included.  Rank 0 alone writes the file (temporary name, then os.replace);
+    every rank returns from the barrier behind it, so the path is readable when this returns."""
     t = Trainer(device=device, ddp=ddp)
     if model_path is not None:
         t.load_weights(model_path)
@@ -233,7 +276,14 @@ def train(model_path, board_x, pi_y, v_y, data_retention, version, save_dir=SAVE
     keep = rng.choice(n, int(data_retention * n), replace=False)
     bx, py, vy = np.asarray(board_x)[keep], np.asarray(pi_y)[keep], np.asarray(v_y)[keep]
     t.fit(bx, py, vy, seed=seed)
-    return t.save_weights(save_dir, MODEL_PREFIX, version)
+    if not ddp:
+        return t.save_weights(save_dir, MODEL_PREFIX, version)
+    import torch.distributed as dist
+    path = '{}/{}{:0>4}-weights.h5'.format(save_dir, MODEL_PREFIX, version)
+    if dist.get_rank() == 0:
+        path = t.save_weights(save_dir, MODEL_PREFIX, version)
+    dist.barrier()
+    return path
 
 
 # ---- the training loop around the path (train.py:235-352) -------------------------------------------------------
@@ -241,6 +291,14 @@ NUM_SELF_PLAY = 180               # config.py:57
 EVAL_GAMES = 24                   # config.py:40
 PAST_ITER_COUNT = 1               # config.py:51
 DEF_DATA_RETENTION_RATE = 0.5     # config.py:52
+
+
+def version_of_filename(filename):
+    """the 4-digit iteration number in a weights file name ('version0016-weights.h5', 'greedy-model0003.h5'), -1 if there is
+    none: what the reference resumes from (utils.py:12-19, train.py:390-394)"""
+    import re
+    m = re.search(r'(%s|%s)([0-9]{4})(-weights|)\.h5' % (MODEL_PREFIX, 'greedy-model'), filename)
+    return int(m.group(2)) if m else -1
 
 
 def get_weights_path_from_version(version, save_dir=SAVE_WEIGHTS_DIR):
@@ -270,33 +328,95 @@ def combine_prev_iters_train_data(board_x, pi_y, v_y, iteration_count, directory
     return [], [], [], 0
 
 
-def evaluate(best_model, cur_model, num_games=EVAL_GAMES, sims=None, seed=None, first_game=0):
+def evaluate(best_model, cur_model, num_games=EVAL_GAMES, sims=None, seed=None, first_game=0, dist=None, device=0):
     """train.evaluate / evaluate_in_parallel (train.py:150-231): num_games with alternating colours and the 100-move
-    limit, all as one batch on the GPU; returns the number of games cur_model won."""
+    limit, all as one batch per GPU (sharded over the ranks of `dist`); returns the number of games cur_model won."""
     from . import arena
     from .config import MCTS_SIMULATIONS
     w_best, w_cur, draws = arena.evaluate(best_model, cur_model, num_games, enforce_move_limit=True,
-                                          sims=MCTS_SIMULATIONS if sims is None else sims, seed=seed, first_game=first_game)
+                                          sims=MCTS_SIMULATIONS if sims is None else sims, seed=seed, first_game=first_game,
+                                          dist=dist, device=device)
     return w_cur
+
+
+def _selfplay_shard(p1, p2, num_self_play, sims, seed, game0, dist, device, data_dir, iteration_count):
+    """this rank's share of an iteration's self-play games -> the iteration's (board_x, pi_y, v_y) on EVERY rank, rows in
+    game-id order (what one GPU playing all the games would return), plus (games kept, games played, expansions)."""
+    import torch
+    from . import selfplay as sp
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    m1, m2 = sp._load_models(p1, p2, device='cuda:%d' % device)
+    mine = len(range(rank, num_self_play, world))
+    sink = sp.TrainDataSink()
+    kept = played = expansions = 0
+    if mine > 0:
+        run = sp.SelfPlayRun(m1, m2, n_games=mine, sims=sims, seed=seed, first_game=game0 + rank, game_stride=world, device=device,
+                             keep_records=False, sink=sink)
+        try:
+            run.run()
+            st = run.store.results['status']
+            from . import _lib
+            kept = int(((st == _lib.ST_WON_P1) | (st == _lib.ST_WON_P2)).sum())
+            played = mine
+            c = run.counters()
+            expansions = c['expansions']
+            if c['errors']:
+                raise _lib.CcspError('%d self-play games ended in ERROR' % c['errors'])
+        finally:
+            run.close()
+    bx, py, vy, gid = sink.arrays(canonical=True, with_games=True)
+    if dist is None:
+        return bx, py, vy, kept, played, expansions
+    # the ranks' rows meet through files of the (node-local) data directory: rows carry their game id, the union is sorted by it
+    from .launch import coll_device
+    shard_dir = os.path.join(data_dir, '.shards')
+    os.makedirs(shard_dir, exist_ok=True)
+    mine_path = os.path.join(shard_dir, 'iter%d-rank%d.npz' % (iteration_count, rank))
+    tmp = mine_path + '.tmp.npz'
+    np.savez(tmp, board_x=bx, pi_y=py, v_y=vy, game=gid)
+    os.replace(tmp, mine_path)
+    t = torch.tensor([kept, played, expansions], dtype=torch.int64, device=coll_device(dist))
+    dist.all_reduce(t)                                    # (also the barrier behind which every shard file is complete)
+    kept, played, expansions = (int(x) for x in t.cpu())
+    parts = [np.load(os.path.join(shard_dir, 'iter%d-rank%d.npz' % (iteration_count, r))) for r in range(world)]
+    bx = np.concatenate([z['board_x'] for z in parts]); py = np.concatenate([z['pi_y'] for z in parts])
+    vy = np.concatenate([z['v_y'] for z in parts]); gid = np.concatenate([z['game'] for z in parts])
+    o = np.argsort(gid, kind='stable')
+    dist.barrier()                                        # everyone has read the shards
+    if rank == 0:
+        for r in range(world):
+            os.remove(os.path.join(shard_dir, 'iter%d-rank%d.npz' % (iteration_count, r)))
+    return bx[o], py[o], vy[o], kept, played, expansions
 
 
 def evolve(cur_model_path, other_opponent_for_selfplay=None, iteration_count=0, best_model=None, iterations=None,
            num_self_play=NUM_SELF_PLAY, eval_games=EVAL_GAMES, sims=None, seed=None, data_dir=None, weights_dir=SAVE_WEIGHTS_DIR,
-           log=print):
+           log=print, dist=None, device=0, timings=None):
     """train.evolve (train.py:235-317): self-play -> convert / augment / save -> pool with the previous iteration ->
     train -> (if a best model is tracked) gate the new weights on more than int(0.55 * eval_games) wins.
-    The reference loops forever; `iterations` bounds it (None = forever).  One iteration's `num_self_play` games are
-    ONE batch on this GPU (generate_self_play_in_parallel's 12 workers, train.py:71-105), the gate's games another.
+    The reference loops forever; `iterations` bounds it (None = forever).
+
+    One GPU (dist=None): an iteration's games run in up to 4096 restarting slots on `device`, the gate's games as one batch.
+    N GPUs: every rank calls this with the same arguments and its own `device` after torch.distributed is initialised
+    (launch.init_rank; `python -m chinesecheckersagent_amd.train --gpus N` starts the ranks): rank r plays the self-play
+    games r, r + N, ... and the arena games r, r + N, ..., the ranks' rows are merged in game-id order (the SAME arrays a
+    single GPU produces), the fit runs under DistributedDataParallel with each rank's share of every batch, and the gate's win
+    counts are all-reduced -- every rank takes the same decision.  Rank 0 writes the data and weight files.
+    `timings` (a list) receives one dict of wall seconds per phase and iteration.
     Returns (cur_model_path, best_model, iteration_count)."""
-    from . import selfplay as sp
+    import time
     from . import utils
     from .config import MCTS_SIMULATIONS, SAVE_TRAIN_DATA_DIR
-    from .model import ResidualCNN
     sims = MCTS_SIMULATIONS if sims is None else sims
     data_dir = SAVE_TRAIN_DATA_DIR if data_dir is None else data_dir
+    rank = dist.get_rank() if dist is not None else 0
+    if rank != 0:
+        log = lambda *a, **k: None                                      # noqa: E731
     done = 0
     game0 = 0
     while iterations is None or done < iterations:
+        tm = {'iteration': iteration_count}
+        t0 = time.time()
         # generate plays (train.py:246-262): current model vs another, or the best model alone, or the current alone
         if other_opponent_for_selfplay is not None:
             p1, p2 = cur_model_path, other_opponent_for_selfplay
@@ -304,40 +424,130 @@ def evolve(cur_model_path, other_opponent_for_selfplay=None, iteration_count=0, 
             p1, p2 = best_model, None
         else:
             p1, p2 = cur_model_path, None
-        m1 = ResidualCNN()
-        if p1 is not None:
-            m1.load_weights(p1)
-        m2 = None
-        if p2 is not None:
-            m2 = ResidualCNN()
-            m2.load_weights(p2)
-        games = sp.selfplay_batch(m1, m2, n_games=num_self_play, sims=sims, seed=seed, first_game=game0)
+        board_x, pi_y, v_y, kept, played, expansions = _selfplay_shard(p1, p2, num_self_play, sims, seed, game0, dist, device,
+                                                                       data_dir, iteration_count)
         game0 += num_self_play
-        games = [(h, r) for h, r in games if h is not None and r is not None and h != 'unfinished']
-        log('iteration %d: %d of %d self-play games kept' % (iteration_count, len(games), num_self_play))
+        tm['selfplay_s'] = time.time() - t0
+        tm['selfplay_games'], tm['selfplay_games_kept'], tm['selfplay_expansions'] = played, kept, expansions
+        log('iteration %d: %d of %d self-play games kept' % (iteration_count, kept, num_self_play))
         # prepare data (train.py:268-285)
-        board_x, pi_y, v_y = utils.convert_to_train_data(games)
-        board_x, pi_y, v_y = utils.augment_train_data(board_x, pi_y, v_y)
+        t0 = time.time()
+        board_x, pi_y, v_y = utils.augment_train_data(list(board_x), list(pi_y), list(v_y))
         board_x, pi_y, v_y = np.array(board_x), np.array(pi_y), np.array(v_y)
-        if len(board_x) > 0 and len(pi_y) > 0 and len(v_y) > 0:
+        if len(board_x) > 0 and len(pi_y) > 0 and len(v_y) > 0 and rank == 0:
             utils.save_train_data(board_x, pi_y, v_y, version=iteration_count, directory=data_dir)
+        if dist is not None:
+            dist.barrier()                                              # the iteration's file is there for every rank
         board_x, pi_y, v_y, used = combine_prev_iters_train_data(board_x, pi_y, v_y, iteration_count, directory=data_dir)
+        tm['data_s'] = time.time() - t0
+        tm['samples'] = int(len(v_y))
         if used == 0:
             log('no training data for iteration %d, re-iterating' % iteration_count)
             done += 1
+            if timings is not None:
+                timings.append(tm)
             continue
         retention = min(1. / used, DEF_DATA_RETENTION_RATE)            # train.py:288
         # train (train.py:294-304; in this process -- there is no TensorFlow session to keep out of it)
-        cur_model_path = train(cur_model_path, board_x, pi_y, v_y, retention, iteration_count, save_dir=weights_dir)
+        t0 = time.time()
+        cur_model_path = train(cur_model_path, board_x, pi_y, v_y, retention, iteration_count, save_dir=weights_dir,
+                               device='cuda:%d' % device if dist is not None else None, ddp=dist is not None)
+        tm['train_s'] = time.time() - t0
         # evaluate (train.py:308-314)
         if best_model is not None:
-            wins = evaluate(best_model, cur_model_path, eval_games, sims=sims, seed=seed, first_game=game0)
+            t0 = time.time()
+            wins = evaluate(best_model, cur_model_path, eval_games, sims=sims, seed=seed, first_game=game0, dist=dist, device=device)
             game0 += eval_games
+            tm['arena_s'] = time.time() - t0
+            tm['arena_wins'] = wins
             if wins > int(0.55 * eval_games):
                 best_model = cur_model_path
                 log('now using %s as the best model (%d/%d wins)' % (best_model, wins, eval_games))
             else:
                 log('iteration %d is not better (%d/%d wins); retaining %s' % (iteration_count, wins, eval_games, best_model))
+        if timings is not None:
+            timings.append(tm)
         iteration_count += 1
         done += 1
     return cur_model_path, best_model, iteration_count
+
+
+def evolve_rank(config_path):
+    """a rank process of evolve_in_parallel (worker.py `evolve`): joins the process group, runs evolve() on its GPU, rank 0
+    writes the result next to the config file"""
+    import json
+    from .launch import init_rank
+    cfg = json.load(open(config_path))
+    rank, world, local, dist = init_rank()
+    timings = []
+    cur, best, it = evolve(dist=dist, device=local, timings=timings, **cfg['evolve'])
+    if rank == 0:
+        with open(cfg['result'] + '.tmp', 'w') as f:
+            json.dump(dict(cur_model_path=cur, best_model=best, iteration_count=it, timings=timings, world=world,
+                           backend=dist.get_backend() if dist is not None else None), f)
+        os.replace(cfg['result'] + '.tmp', cfg['result'])
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def evolve_in_parallel(n_gpus, cur_model_path, devices=None, work_dir=None, **kw):
+    """train.evolve over `n_gpus` MI355X (BASELINE config 5): starts one rank process per GPU from THIS process, which never
+    touches the GPU, and returns (cur_model_path, best_model, iteration_count, timings) of the run.  kw = evolve()'s arguments."""
+    import json
+    import sys
+    import tempfile
+    from . import launch
+    tmp = None
+    if work_dir is None:
+        tmp = tempfile.TemporaryDirectory(prefix='ccsp-evolve-')
+        work_dir = tmp.name
+    try:
+        cfg = os.path.join(work_dir, 'evolve-config.json')
+        result = os.path.join(work_dir, 'evolve-result.json')
+        kw = dict(kw, cur_model_path=cur_model_path)
+        kw.pop('log', None)
+        with open(cfg, 'w') as f:
+            json.dump(dict(evolve=kw, result=result), f)
+        extra = {'PYTHONPATH': os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
+                                               ([os.environ['PYTHONPATH']] if os.environ.get('PYTHONPATH') else []))}
+        if devices is not None and len(set(devices)) < len(devices):
+            extra['CCSP_ONE_DEVICE'] = '1'
+        rc = launch.run_ranks([sys.executable, '-m', 'chinesecheckersagent_amd.worker', 'evolve', '--config', cfg], n_gpus,
+                              devices=devices, extra_env=extra)
+        if rc:
+            raise RuntimeError('evolve_in_parallel: a rank process failed (exit code %d)' % rc)
+        r = json.load(open(result))
+        return r['cur_model_path'], r['best_model'], r['iteration_count'], r['timings']
+    finally:
+        if tmp is not None:
+            tmp.cleanup()
+
+
+if __name__ == '__main__':
+    # python -m chinesecheckersagent_amd.train [-c weights.h5] [-b best.h5] [-p opponent.h5] --gpus N --iterations K ...
+    # (the flags of the reference's train.py:368-380 plus the sizes it keeps in config.py)
+    import argparse
+    ap = argparse.ArgumentParser(description='self-play -> train -> arena loop on N MI355X (train.py:235-317)')
+    ap.add_argument('-c', '--cur_model_path', default=None)
+    ap.add_argument('-b', '--best_model_path', default=None)
+    ap.add_argument('-p', '--opponent', default=None)
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--iterations', type=int, default=1)
+    ap.add_argument('--num-self-play', type=int, default=NUM_SELF_PLAY)
+    ap.add_argument('--eval-games', type=int, default=EVAL_GAMES)
+    ap.add_argument('--sims', type=int, default=None)
+    ap.add_argument('--seed', type=int, default=None)
+    ap.add_argument('--data-dir', default=None)
+    ap.add_argument('--weights-dir', default=SAVE_WEIGHTS_DIR)
+    a = ap.parse_args()
+    it0 = 0
+    if a.cur_model_path is not None:
+        it0 = version_of_filename(a.cur_model_path) + 1                  # train.py:390-394
+    cur, best, it, timings = evolve_in_parallel(a.gpus, a.cur_model_path, other_opponent_for_selfplay=a.opponent, iteration_count=it0,
+                                                best_model=a.best_model_path, iterations=a.iterations, num_self_play=a.num_self_play,
+                                                eval_games=a.eval_games, sims=a.sims, seed=a.seed, data_dir=a.data_dir,
+                                                weights_dir=a.weights_dir)
+    for tm in timings:
+        print(tm)
+    print('current model: %s; best model: %s; next iteration: %d' % (cur, best, it))

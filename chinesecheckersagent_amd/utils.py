@@ -107,7 +107,7 @@ def states_to_model_input(states, players):
     return out.reshape(n, BOARD_WIDTH, BOARD_HEIGHT, BOARD_HIST_MOVES * 2 + 1)
 
 
-def log_to_train_data(states, meta, pi, results, first_game=0, game_stride=1, randomised=False):
+def log_to_train_data(states, meta, pi, results, first_game=0, game_stride=1, randomised=False, return_games=False):
     """The engine's sample log + result table -> (board_x [N,7,7,7] f64, pi_y [N,294] f64, v_y [N] int64) without a
     Python object per position: convert_to_train_data(collect()) for large batches.  Same rows in the same order
     (games by id, plies in order; won games only; the first BOARD_HIST_MOVES rows of a randomised game dropped,
@@ -131,6 +131,8 @@ def log_to_train_data(states, meta, pi, results, first_game=0, game_stride=1, ra
     board_x = states_to_model_input(np.asarray(states)[sel], label_player)
     reward = np.asarray(results['reward'], dtype=np.int64)[k[keep]]
     v_y = np.where(j % 2 == 0, reward, -reward).astype(np.int64)
+    if return_games:                                                 # + the game id of every row (rows of a game are contiguous, in ply order)
+        return board_x, np.asarray(pi, dtype=np.float64)[sel], v_y, g[keep]
     return board_x, np.asarray(pi, dtype=np.float64)[sel], v_y
 
 

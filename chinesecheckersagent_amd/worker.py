@@ -1,0 +1,91 @@
+"""A rank process of the N-GPU generator: one MI355X, its share of the game ids (train.generate_self_play's role,
+train.py:27-67, with a GPU instead of a CPU core).
+
+    python -m chinesecheckersagent_amd.worker selfplay --model M.h5 --games N --sims S --seed Z --first-game F --out DIR
+
+started by launch.run_ranks with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment.  Rank r of R plays ids
+F + j for j = r, r + R, ... < N -- a game's record depends on its id alone, so the union over the ranks is what ONE GPU
+would have played.  Every rank leaves DIR/selfplay-rank{r}.npz (the sample rows and results of its games); the ranks'
+counters and root visit-count histograms meet in ONE all-reduce (RCCL over xGMI) and rank 0 writes
+DIR/summary.json.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+
+def selfplay_rank(a):
+    import torch
+    from . import _lib, summary
+    from . import selfplay as sp
+    from .launch import coll_device, init_rank
+    rank, world, local, dist = init_rank()
+    _lib.require_gpu()
+    model, model2 = sp._load_models(a.model, a.model2, device='cuda:%d' % local)
+    n_mine = len(range(rank, a.games, world))
+    out = dict(rank=rank, world=world, games=n_mine)
+    hist = np.zeros(_lib.NUM_ACTIONS, dtype=np.uint64)
+    counters = {}
+    if n_mine > 0:
+        run = sp.SelfPlayRun(model, model2, n_games=n_mine, sims=a.sims, seed=a.seed, randomised=a.randomised,
+                             first_game=a.first_game + rank, game_stride=world, device=local, max_slots=a.max_slots)
+        try:
+            run.run()
+            counters = run.counters()
+            parts = run.b.parts if hasattr(run.b, 'parts') else [run.b]
+            for b in parts:
+                hist += b.eng.visit_histogram()
+            store = run.store
+            store.take_finished()
+            rows = list(store._records)
+            if rows:
+                st, meta, pi = (np.concatenate([x[i] for x in rows]) for i in range(3))
+            else:
+                st, meta, pi = np.zeros(0, dtype=_lib.STATE_DTYPE), np.zeros(0, dtype=_lib.META_DTYPE), np.zeros((0, _lib.NUM_ACTIONS))
+            np.savez(os.path.join(a.out, 'selfplay-rank%d.npz' % rank), state=st, meta=meta, pi=pi, results=store.results,
+                     first_game=a.first_game + rank, game_stride=world)
+        finally:
+            run.close()
+    tot, hist_all = counters, hist
+    if dist is not None:
+        tot, hist_all = summary.allreduce_summary(counters, hist, dist, device=coll_device(dist))
+        dist.barrier()
+    if rank == 0:
+        out.update(world=world, counters=tot, visit_histogram=[int(x) for x in hist_all],
+                   backend=dist.get_backend() if dist is not None else None)
+        with open(os.path.join(a.out, 'summary.json'), 'w') as f:
+            json.dump(out, f)
+    if dist is not None:
+        dist.destroy_process_group()
+    torch.cuda.synchronize()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog='python -m chinesecheckersagent_amd.worker')
+    sub = ap.add_subparsers(dest='task', required=True)
+    s = sub.add_parser('selfplay')
+    s.add_argument('--model', default=None)
+    s.add_argument('--model2', default=None)
+    s.add_argument('--games', type=int, required=True)
+    s.add_argument('--sims', type=int, required=True)
+    s.add_argument('--seed', type=int, required=True)
+    s.add_argument('--first-game', type=int, default=0)
+    s.add_argument('--max-slots', type=int, default=4096)
+    s.add_argument('--randomised', action='store_true')
+    s.add_argument('--out', required=True)
+    e = sub.add_parser('evolve')
+    e.add_argument('--config', required=True, help='JSON file with the arguments of train.evolve')
+    a = ap.parse_args(argv)
+    if a.task == 'selfplay':
+        selfplay_rank(a)
+    else:
+        from . import train
+        train.evolve_rank(a.config)
+
+
+if __name__ == '__main__':
+    main()
+    sys.exit(0)

@@ -13,7 +13,8 @@
  *   - every function returns 0 on success, a negative CCSP_E* code otherwise; nothing throws
  *     or aborts (the reference's `assert`s -- MCTS.py:80,151; selfplay.py:38,113,118 -- become
  *     per-game status CCSP_ST_ERROR);
- *   - all launches are asynchronous and stream-ordered; a context is not thread-safe;
+ *   - all launches are asynchronous and stream-ordered; a context is not thread-safe; every entry point runs on the
+ *     context's own device and puts the caller's current device back before it returns;
  *   - the caller owns every buffer it passes; the library keeps device memory only inside a
  *     ccsp_ctx between ccsp_create() and ccsp_destroy();
  *   - random draws are a pure function of (seed, global game id, ply, simulation, depth,
@@ -253,6 +254,9 @@ int ccsp_read_counters(ccsp_ctx *ctx, uint64_t *out /* [CCSP_CNT_COUNT] */);
 int ccsp_read_visit_histogram(ccsp_ctx *ctx, uint64_t *out /* [294]: sum of root visit counts per action */);
 int ccsp_read_slots(ccsp_ctx *ctx, uint8_t *status, uint32_t *ply, uint64_t *game, ccsp_state *state, uint8_t *player);
 int ccsp_log_size(ccsp_ctx *ctx, uint64_t *n);
+/* forget the rows read so far (stream-ordered): a caller that harvests the log every H plies needs n_slots x H rows of
+ * capacity whatever the number of games (train.generate_self_play's list of games grows on the host, train.py:61-64) */
+int ccsp_log_clear(ccsp_ctx *ctx, void *stream);
 int ccsp_log_device_ptrs(ccsp_ctx *ctx, ccsp_state **state, ccsp_sample_meta **meta, double **pi);   /* device pointers */
 int ccsp_read_log(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_state *state, ccsp_sample_meta *meta, double *pi);
 int ccsp_read_results(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_game_result *out);

@@ -126,7 +126,7 @@ def _ddp_rank(rank, world, port, q):
     zs = np.ones(42, dtype=np.int64)
     seen = []
     step0 = t.step
-    t.step = lambda a, b, c: (seen.append(a.clone()), step0(a, b, c))[1]
+    t.step = lambda a, b, c, **kw: (seen.append(a.clone()), step0(a, b, c, **kw))[1]
     t.fit(xs, ps, zs, batch_size=8, epochs=1, validation_split=0.0, seed=5)
     rows = torch.cat(seen)
     q.put((rank, float(t.net.policy_head.weight.sum()), float(t.net.convs['5'].weight.abs().sum()), [len(a) for a in seen],
@@ -141,11 +141,74 @@ def test_ddp_gloo_world2_keeps_replicas_identical():
     port = 29600 + os.getpid() % 1000
     ps = [ctx.Process(target=_ddp_rank, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in ps]
-    res = sorted(q.get(timeout=180) for _ in ps)
+    res = sorted(q.get(timeout=60) for _ in ps)
     [p.join(60) for p in ps]
     assert res[0][1:3] == res[1][1:3]                      # gradient all-reduce: both replicas took the same steps
     # 42 samples in global batches of 8: 5 x 4 per rank, then 2 -> 1 per rank; the two ranks saw DIFFERENT rows
     assert res[0][3] == res[1][3] == [4, 4, 4, 4, 4, 1] and res[0][4] != res[1][4]
+
+
+def _fit_data(n=43):
+    import torch
+    gc = torch.Generator().manual_seed(7)
+    xs = torch.randint(0, 7, (n, 7, 7, 7), generator=gc).float().numpy()
+    ps = torch.softmax(torch.randn(n, 294, generator=gc), dim=1).numpy()
+    zs = (torch.randint(0, 2, (n,), generator=gc) * 2 - 1).numpy().astype(np.int64)
+    return xs, ps, zs
+
+
+def _ddp_fit_rank(rank, world, port, q, save_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from chinesecheckersagent_amd import train as T
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    xs, ps, zs = _fit_data()
+    torch.manual_seed(1)
+    t = T.Trainer(device='cpu', ddp=True)
+    t.fit(xs, ps, zs, batch_size=8, epochs=2, validation_split=0.0, seed=5)
+    state = {k: v.copy() for k, v in t.state_as_keras().items()}
+    # train(): rank 0 alone writes the file, every rank returns behind the barrier with a readable path
+    torch.manual_seed(1)
+    path = T.train(None, xs, ps, zs, 1.0, 7, save_dir=save_dir, device='cpu', seed=5, ddp=True)
+    t2 = T.Trainer(device='cpu')
+    t2.load_weights(path)
+    q.put((rank, state, {k: v.copy() for k, v in t2.state_as_keras().items()}, sorted(os.listdir(save_dir))))
+    dist.destroy_process_group()
+
+
+def test_ddp_world2_fit_equals_the_single_process_fit(tmp_path):
+    """under ddp the BatchNormalization statistics are those of the GLOBAL batch and unequal shares are weighted,
+    so two ranks take the step one process takes on the whole batch -- weights AND moving statistics; train(ddp=True) leaves ONE
+    whole file written by rank 0."""
+    import torch
+    import torch.multiprocessing as mp
+    from chinesecheckersagent_amd import train as T
+    xs, ps, zs = _fit_data()                               # 43 rows, batches of 8: the last one has 3 rows = shares of 2 and 1
+    torch.manual_seed(1)
+    single = T.Trainer(device='cpu')
+    single.fit(xs, ps, zs, batch_size=8, epochs=2, validation_split=0.0, seed=5)
+    want = single.state_as_keras()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 1000
+    save_dir = str(tmp_path / 'w')
+    ps_ = [ctx.Process(target=_ddp_fit_rank, args=(r, 2, port, q, save_dir)) for r in range(2)]
+    [p.start() for p in ps_]
+    res = sorted((q.get(timeout=300) for _ in ps_), key=lambda r: r[0])
+    [p.join(60) for p in ps_]
+    for name, w in want.items():
+        for rank, state, _, _ in res:
+            scale = max(1.0, float(np.abs(w).max()))
+            assert np.abs(state[name] - w).max() < 2e-5 * scale, (name, rank, np.abs(state[name] - w).max())
+        assert np.array_equal(res[0][1][name], res[1][1][name]), name          # replicas bit-identical, moving statistics included
+    moved = [n for n in want if 'moving_mean' in n and np.abs(want[n]).max() > 0]
+    assert len(moved) == 30                                                     # the statistics did move
+    # the file: one, whole, the same on both ranks, equal to rank 0's replica after the SAME fit from the same initial weights
+    assert res[0][3] == res[1][3] == ['version0007-weights.h5']
+    for name in want:
+        assert np.array_equal(res[0][2][name], res[1][2][name])
 
 
 def test_iteration_pooling_and_paths(tmp_path):
