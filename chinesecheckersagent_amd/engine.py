@@ -134,6 +134,30 @@ class SelfPlayEngine(object):
             check(self.L.ccsp_read_log(self.ctx, first, n, state.ctypes.data, meta.ctypes.data, pi.ctypes.data), 'ccsp_read_log')
         return state, meta, pi
 
+    def host_log_buffers(self, rows=None):
+        """page-locked host arrays (state, meta, pi) of `rows` rows (default: the log's capacity) for log_into(): a device-to-host
+        copy into pinned memory runs at PCIe speed, into fresh pageable NumPy memory at a fraction of it"""
+        import torch
+        rows = self.log_capacity if rows is None else int(rows)
+
+        def pinned(dtype, shape):
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            raw = torch.empty(max(n, 1), dtype=torch.uint8, pin_memory=True)
+            return raw.numpy()[:n].view(dtype).reshape(shape), raw
+        st, k0 = pinned(STATE_DTYPE, (rows,))
+        meta, k1 = pinned(META_DTYPE, (rows,))
+        pi, k2 = pinned(np.float64, (rows, NUM_ACTIONS))
+        return dict(state=st, meta=meta, pi=pi, rows=rows, keep=(k0, k1, k2))
+
+    def log_into(self, bufs, first=0):
+        """the log rows from `first` on, copied into the arrays of host_log_buffers(); -> (state, meta, pi) views of the rows read"""
+        n = self.log_size() - first
+        assert n <= bufs['rows']
+        if n:
+            check(self.L.ccsp_read_log(self.ctx, first, n, bufs['state'].ctypes.data, bufs['meta'].ctypes.data, bufs['pi'].ctypes.data),
+                  'ccsp_read_log')
+        return bufs['state'][:n], bufs['meta'][:n], bufs['pi'][:n]
+
     def log_clear(self, stream=None):
         """forget the rows read so far (stream-ordered): the log is empty again"""
         check(self.L.ccsp_log_clear(self.ctx, _stream_ptr(stream)), 'ccsp_log_clear')

@@ -111,6 +111,7 @@ class H5File(object):
     def _dataset(self, header):
         shape = dtype = None
         addr = size = None
+        chunked = None
         for mtype, data, msize in self._messages(header):
             b = self.buf
             if mtype == 0x01:                                   # dataspace
@@ -132,9 +133,13 @@ class H5File(object):
                     raise H5Error('datatype class %d not supported' % cls)
             elif mtype == 0x08:                                 # layout
                 ver = b[data]
-                if ver == 3:
+                if ver == 3 and b[data + 1] == 2:               # chunked: B-tree v1 of raw data chunks
+                    nd = b[data + 2]
+                    chunked = (self._u64(data + 3), tuple(self._u32(data + 11 + 4 * i) for i in range(nd)))
+                    addr = 0
+                elif ver == 3:
                     if b[data + 1] != 1:
-                        raise H5Error('only contiguous layout supported')
+                        raise H5Error('only contiguous and chunked layouts supported')
                     addr, size = self._u64(data + 2), self._u64(data + 10)
                 else:
                     raise H5Error('layout version %d not supported' % ver)
@@ -142,10 +147,45 @@ class H5File(object):
                 raise H5Error('filtered data not supported')
         if shape is None or dtype is None or addr is None:
             return None
+        if chunked is not None:
+            return self._read_chunked(shape, dtype, chunked[0], chunked[1])
         if addr == UNDEF:
             return np.zeros(shape, dtype=dtype)
         n = int(np.prod(shape)) if shape else 1
         return np.frombuffer(self.buf, dtype=dtype, count=n, offset=self.base + addr).reshape(shape).copy()
+
+    def _chunks(self, addr, nd):
+        """yield (offsets, address) of the raw data chunks below a type-1 B-tree node"""
+        b = self.buf
+        if addr == UNDEF:
+            return
+        if b[addr:addr + 4] != b'TREE' or b[addr + 4] != 1:
+            raise H5Error('bad chunk B-tree node')
+        level, used = b[addr + 5], self._u16(addr + 6)
+        ks = 8 + 8 * nd
+        p = addr + 24
+        for i in range(used):
+            key, child = p + i * (ks + 8), self._u64(p + i * (ks + 8) + ks)
+            if level > 0:
+                for x in self._chunks(child, nd):
+                    yield x
+            else:
+                if self._u32(key + 4) != 0:
+                    raise H5Error('filtered chunks not supported')
+                yield tuple(self._u64(key + 8 + 8 * j) for j in range(nd - 1)), child
+
+    def _read_chunked(self, shape, dtype, btree, cdims):
+        nd = len(cdims)
+        if nd != len(shape) + 1:
+            raise H5Error('chunk rank does not match the dataspace')
+        cshape = tuple(cdims[:-1])
+        out = np.zeros(shape, dtype=dtype)
+        n = int(np.prod(cshape))
+        for off, addr in self._chunks(btree, nd):
+            c = np.frombuffer(self.buf, dtype=dtype, count=n, offset=self.base + addr).reshape(cshape)
+            sl = tuple(slice(o, min(o + cs, d)) for o, cs, d in zip(off, cshape, shape))
+            out[sl] = c[tuple(slice(0, s_.stop - s_.start) for s_ in sl)]
+        return out
 
     def get(self, path):
         """dataset at 'a/b/c' as a numpy array"""
@@ -238,7 +278,8 @@ def write_datasets(path, datasets):
         data_addr.append(pos)
         pos += a.nbytes + (-a.nbytes % 8)
     eof = pos
-    out = bytearray(eof)
+    meta_end = data_addr[0] if arrays else eof
+    out = bytearray(meta_end)                         # metadata only: the arrays go to the file straight from their buffers
     # superblock v0
     out[0:8] = SIG
     struct.pack_into('<BBBBBBBBHHI', out, 8, 0, 0, 0, 0, 0, 8, 8, 0, LEAF_K, K, 0)
@@ -277,9 +318,191 @@ def write_datasets(path, datasets):
         body += struct.pack('<HHB3x', 0x08, len(_pad8(lay)), 0) + _pad8(lay)
         struct.pack_into('<BBHII4x', out, h, 1, 0, 3, 1, len(body))
         out[h + 16:h + 16 + len(body)] = body
-        out[data_addr[i]:data_addr[i] + a.nbytes] = a.tobytes()
     with open(path, 'wb') as f:
-        f.write(bytes(out))
+        f.write(out)
+        for i, a in enumerate(arrays):
+            f.seek(data_addr[i])
+            if a.nbytes:
+                f.write(memoryview(a.reshape(-1)).cast('B'))
+        f.truncate(eof)
+
+
+# ---------------------------------------------------------------------------------------------
+# streaming writer: the same flat file of datasets in the root group, but CHUNKED along the first axis (layout class 2 with
+# a version-1 B-tree of raw data chunks per dataset), so that rows can be appended while a run is still producing them --
+# the self-play generator streams finished games to the training file while the GPU plays on, host memory bounded by
+# one chunk.  h5py / the reference's train.py read it like any dataset (f['board_x'], np.array(f.get('pi_y'))).
+
+class StreamWriter(object):
+    """specs: ordered [(name, row shape, dtype)]; append(list of arrays with the same number of rows); close().
+    Chunks of `chunk_rows` rows are written as they fill up; all metadata that depends on the row count (dataspace, chunk
+    B-trees) is written by close().  The file appears under its name when close() has finished (temporary name before)."""
+
+    ISTORE_K = 32                      # B-tree node K of chunked storage under a version-0 superblock (the library's default)
+
+    def __init__(self, path, specs, chunk_rows=4096):
+        import os
+        self.path, self.tmp = path, '%s.tmp%d' % (path, os.getpid())
+        self.names = [n for n, _, _ in specs]
+        self.row_shapes = [tuple(int(x) for x in sh) for _, sh, _ in specs]
+        self.dtypes = [np.dtype(dt).newbyteorder('<') for _, _, dt in specs]
+        self.chunk_rows = int(chunk_rows)
+        self.rows = 0                                    # rows appended
+        self.flushed = 0                                 # rows written out as full chunks
+        self._buf = [np.zeros((self.chunk_rows,) + sh, dtype=dt) for sh, dt in zip(self.row_shapes, self.dtypes)]
+        self._fill = 0
+        self._chunks = [[] for _ in specs]               # per dataset: file address of every chunk, in row order
+        if len(self.names) > 8:
+            raise H5Error('too many datasets for one symbol node')
+        # fixed-size metadata at the start: superblock | root header | heap | group B-tree | symbol node | dataset headers
+        pos = 96
+        self.root_hdr = pos; pos += 16 + 24
+        self.heap = pos
+        self.heap_data_size = max(24, (8 + sum(len(n) + 1 for n in self.names) + 7) // 8 * 8)
+        pos += 32
+        self.heap_data = pos; pos += self.heap_data_size
+        self.btree = pos; pos += 8 + 16 + (2 * 16 + 1) * 8 + 2 * 16 * 8
+        self.snod = pos; pos += 8 + 2 * 4 * 40
+        self.hdrs = []
+        for sh in self.row_shapes:
+            self.hdrs.append(pos)
+            pos += 16 + self._header_body_size(len(sh) + 1)
+        pos += -pos % 8
+        self.pos = pos                                   # where the next chunk goes
+        self.f = open(self.tmp, 'wb')
+        self.f.write(b'\0' * pos)
+
+    @staticmethod
+    def _header_body_size(rank):
+        ds = 8 + 8 * rank
+        lay = 3 + 8 + 4 * (rank + 1)
+        return (8 + ds) + (8 + 24) + (8 + (lay + 7) // 8 * 8)       # dataspace, datatype (16-24 bytes padded to 24), layout
+
+    def append(self, arrays):
+        n = len(arrays[0])
+        done = 0
+        while done < n:
+            take = min(n - done, self.chunk_rows - self._fill)
+            for b, a in zip(self._buf, arrays):
+                b[self._fill:self._fill + take] = a[done:done + take]
+            self._fill += take
+            done += take
+            if self._fill == self.chunk_rows:
+                self._emit()
+        self.rows += n
+
+    def _emit(self):
+        for i, b in enumerate(self._buf):
+            self._chunks[i].append(self.pos)
+            self.f.write(memoryview(b.reshape(-1)).cast('B'))
+            self.pos += b.nbytes
+        self.flushed += self._fill
+        self._fill = 0
+
+    def _btree(self, out, i):
+        """the chunk B-tree of dataset i appended to `out` (a bytearray positioned at file offset self.pos); -> root address"""
+        nd = len(self.row_shapes[i]) + 2                                  # rank of the dataset + the element-size dimension
+        ks = 8 + 8 * nd
+        node_size = 24 + (2 * self.ISTORE_K + 1) * ks + 2 * self.ISTORE_K * 8
+        nbytes = self._buf[i].nbytes
+        level = 0
+        entries = [(r * self.chunk_rows, addr) for r, addr in enumerate(self._chunks[i])]      # (first row, child address)
+        if not entries:
+            return UNDEF
+        end_row = len(entries) * self.chunk_rows
+        while True:
+            nodes = []
+            for g in range(0, len(entries), 2 * self.ISTORE_K):
+                grp = entries[g:g + 2 * self.ISTORE_K]
+                addr = self.pos + len(out)
+                node = bytearray(node_size)
+                node[0:4] = b'TREE'
+                struct.pack_into('<BBHQQ', node, 4, 1, level, len(grp), UNDEF, UNDEF)
+                p = 24
+                for row, child in grp:
+                    struct.pack_into('<II', node, p, nbytes, 0)
+                    struct.pack_into('<Q', node, p + 8, row)                 # offsets: (row, 0, ..., 0)
+                    struct.pack_into('<Q', node, p + ks, child)
+                    p += ks + 8
+                nxt = entries[g + len(grp)][0] if g + len(grp) < len(entries) else end_row
+                struct.pack_into('<II', node, p, 0, 0)
+                struct.pack_into('<Q', node, p + 8, nxt)                     # the key behind the last child
+                nodes.append((grp[0][0], addr))
+                out += node
+            # siblings of this level
+            for j, (_, addr) in enumerate(nodes):
+                off = addr - self.pos
+                struct.pack_into('<QQ', out, off + 8, nodes[j - 1][1] if j else UNDEF, nodes[j + 1][1] if j + 1 < len(nodes) else UNDEF)
+            if len(nodes) == 1:
+                return nodes[0][1]
+            entries, level = nodes, level + 1
+
+    def close(self):
+        import os
+        if self.f is None:
+            return self.path
+        if self._fill:                                                       # the last, partly filled chunk (its tail is never read)
+            for b in self._buf:
+                b[self._fill:] = 0
+            self._emit()
+        tail = bytearray()
+        roots = [self._btree(tail, i) for i in range(len(self.names))]
+        self.f.write(tail)
+        eof = self.pos + len(tail)
+        out = bytearray(self.hdrs[-1] + 16 + self._header_body_size(len(self.row_shapes[-1]) + 1) if self.hdrs else self.snod + 8 + 320)
+        K, LEAF_K = 16, 4
+        out[0:8] = SIG
+        struct.pack_into('<BBBBBBBBHHI', out, 8, 0, 0, 0, 0, 0, 8, 8, 0, LEAF_K, K, 0)
+        struct.pack_into('<QQQQ', out, 24, 0, UNDEF, eof, UNDEF)
+        struct.pack_into('<QQII', out, 56, 0, self.root_hdr, 1, 0)
+        struct.pack_into('<QQ', out, 80, self.btree, self.heap)
+        struct.pack_into('<BBHII4x', out, self.root_hdr, 1, 0, 1, 1, 24)
+        struct.pack_into('<HHB3xQQ', out, self.root_hdr + 16, 0x11, 16, 0, self.btree, self.heap)
+        out[self.heap:self.heap + 4] = b'HEAP'
+        struct.pack_into('<B3xQQQ', out, self.heap + 4, 0, self.heap_data_size, 1, self.heap_data)
+        order = sorted(range(len(self.names)), key=lambda i: self.names[i])
+        offs, p = {}, 8
+        for i in order:
+            nb = self.names[i].encode() + b'\0'
+            out[self.heap_data + p:self.heap_data + p + len(nb)] = nb
+            offs[i] = p
+            p += len(nb)
+        out[self.btree:self.btree + 4] = b'TREE'
+        struct.pack_into('<BBHQQ', out, self.btree + 4, 0, 0, 1, UNDEF, UNDEF)
+        struct.pack_into('<QQQ', out, self.btree + 24, 0, self.snod, offs[order[-1]] if order else 0)
+        out[self.snod:self.snod + 4] = b'SNOD'
+        struct.pack_into('<BBH', out, self.snod + 4, 1, 0, len(self.names))
+        q = self.snod + 8
+        for i in order:
+            struct.pack_into('<QQII16x', out, q, offs[i], self.hdrs[i], 0, 0)
+            q += 40
+        for i, sh in enumerate(self.row_shapes):
+            dims = (self.rows,) + sh
+            ds = struct.pack('<BBBB4x', 1, len(dims), 0, 0) + b''.join(struct.pack('<Q', d) for d in dims)
+            body = struct.pack('<HHB3x', 0x01, len(_pad8(ds)), 0) + _pad8(ds)
+            dtm = _dtype_msg(self.dtypes[i])
+            dtm = dtm + b'\0' * (24 - len(dtm))
+            body += struct.pack('<HHB3x', 0x03, 24, 1) + dtm
+            cd = (self.chunk_rows,) + sh + (self.dtypes[i].itemsize,)
+            lay = struct.pack('<BBBQ', 3, 2, len(cd), roots[i]) + b''.join(struct.pack('<I', d) for d in cd)
+            body += struct.pack('<HHB3x', 0x08, len(_pad8(lay)), 0) + _pad8(lay)
+            assert len(body) == self._header_body_size(len(dims))
+            struct.pack_into('<BBHII4x', out, self.hdrs[i], 1, 0, 3, 1, len(body))
+            out[self.hdrs[i] + 16:self.hdrs[i] + 16 + len(body)] = body
+        self.f.seek(0)
+        self.f.write(out)
+        self.f.close()
+        self.f = None
+        os.replace(self.tmp, self.path)
+        return self.path
+
+    def abort(self):
+        import os
+        if self.f is not None:
+            self.f.close()
+            self.f = None
+            if os.path.exists(self.tmp):
+                os.remove(self.tmp)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -164,11 +164,21 @@ class BatchSelfPlay(object):
                 break
         return self.collect()
 
+    HOST_RING = 4            # page-locked host copies of the log in rotation: a harvest's arrays stay valid for the next three
+
     def harvest(self):
         """the rows logged since the last harvest and the result table as it stands, as ONE part:
-        [(state, meta, pi, results, first_game, game_stride)]; the device log is empty again afterwards"""
+        [(state, meta, pi, results, first_game, game_stride)]; the device log is empty again afterwards.  The row arrays are
+        views of page-locked host buffers used in rotation: valid until HOST_RING - 1 further harvests have been taken."""
         e = self.eng
-        st, meta, pi = e.log()
+        if not hasattr(self, '_ring'):
+            self._ring, self._ring_at = [], 0
+        k = self._ring_at % self.HOST_RING
+        if k >= len(self._ring):
+            self._ring.append(e.host_log_buffers())
+        bufs = self._ring[k]
+        self._ring_at += 1
+        st, meta, pi = e.log_into(bufs)
         e.log_clear()
         return [(st, meta, pi, e.results(), e.first_game, e.game_stride)]
 
@@ -304,7 +314,9 @@ class PipelinedSelfPlay(object):
 class GameStore(object):
     """Host side of a harvested run: the sample rows of the games still being played, the result of every game that
     has ended (by GLOBAL game index j: id = first_game + j * game_stride) and what became of the finished games' rows --
-    kept as records (the object path: selfplay()'s play_history) and / or handed on as (board_x, pi_y, v_y) chunks."""
+    kept as records (the object path: selfplay()'s play_history) and / or handed on as (board_x, pi_y, v_y) chunks.
+    A harvest's rows stay together as one batch with an index sorted by game, so that taking the rows of the games that
+    have just ended costs a binary search per batch -- not a pass over every row still waiting."""
 
     def __init__(self, n_games, first_game, game_stride, randomised, keep_records=True):
         self.n_games, self.first_game, self.game_stride = int(n_games), int(first_game), int(game_stride)
@@ -312,26 +324,29 @@ class GameStore(object):
         self.results = np.zeros(self.n_games, dtype=_lib.RESULT_DTYPE)
         self.results['status'] = 0xFF                                    # not finished yet (ccsp_reset's fill)
         self.keep_records = keep_records
-        self._pending = None                                             # rows of games without a result yet
-        self._records = []                                               # rows of finished games (object path)
+        self._batches = []                                               # harvests with rows of games that have not ended yet
+        self._new = []                                                   # indices of the games that ended since the last take
+        self._records = []                                               # rows of finished (won) games (object path)
         self.rows_seen = 0
 
     def add(self, parts):
-        """parts = the harvest() of a batch: rows are appended to the pending set, result tables merged by global index"""
-        new = []
+        """parts = the harvest() of a batch: the rows become a batch of their own (copied: harvest() hands out views of host
+        buffers in rotation), the result tables are merged by global index"""
         for st, meta, pi, res, first, stride in parts:
             j0 = (first - self.first_game) // self.game_stride              # part-local index k <-> global index j0 + k * step
             step = stride // self.game_stride
             j = j0 + np.arange(len(res)) * step
-            ok = j < self.n_games
-            self.results[j[ok]] = res[ok]
+            ended = (res['status'] != 0xFF) & (j < self.n_games)
+            j = j[ended]
+            fresh = self.results['status'][j] == 0xFF
+            self.results[j[fresh]] = res[ended][fresh]
+            if fresh.any():
+                self._new.append(j[fresh])
             if len(meta):
-                new.append((st, meta, pi))
+                g = (np.asarray(meta['game'], dtype=np.int64) - self.first_game) // self.game_stride
+                order = np.argsort(g, kind='stable')                        # a game's rows of this harvest stay in log (= ply) order
+                self._batches.append(dict(st=np.array(st), meta=np.array(meta), pi=np.array(pi), order=order, g=g[order], live=len(meta)))
                 self.rows_seen += len(meta)
-        if self._pending is not None:
-            new.insert(0, self._pending)
-        if new:
-            self._pending = tuple(np.concatenate([x[i] for x in new]) for i in range(3)) if len(new) > 1 else new[0]
 
     def finished(self):
         return bool((self.results['status'] != 0xFF).all())
@@ -339,19 +354,48 @@ class GameStore(object):
     def n_finished(self):
         return int((self.results['status'] != 0xFF).sum())
 
+    def _take_rows(self, games_all, games_won):
+        """rows of the games `games_won` out of every batch (both sorted index arrays); the rows of `games_all` (won and
+        discarded) leave the batches' accounts"""
+        out = []
+        keep = []
+        for b in self._batches:
+            lo, hi = np.searchsorted(b['g'], games_all, 'left'), np.searchsorted(b['g'], games_all, 'right')
+            b['live'] -= int((hi - lo).sum())
+            lo, hi = np.searchsorted(b['g'], games_won, 'left'), np.searchsorted(b['g'], games_won, 'right')
+            cnt = hi - lo
+            tot = int(cnt.sum())
+            if tot:
+                idx = np.repeat(lo - (np.cumsum(cnt) - cnt), cnt) + np.arange(tot)
+                rows = np.sort(b['order'][idx])                              # log order within the batch
+                out.append((b['st'][rows], b['meta'][rows], b['pi'][rows]))
+            if b['live'] > 0:
+                if b['live'] * 4 < len(b['g']) and len(b['g']) > 1024:       # mostly consumed: keep the live rows only
+                    alive = self.results['status'][b['g']] == 0xFF
+                    rows = np.sort(b['order'][alive])
+                    g = b['g'][alive]
+                    st, meta, pi = b['st'][rows], b['meta'][rows], b['pi'][rows]
+                    g2 = (np.asarray(meta['game'], dtype=np.int64) - self.first_game) // self.game_stride
+                    order = np.argsort(g2, kind='stable')
+                    b = dict(st=st, meta=meta, pi=pi, order=order, g=g2[order], live=len(meta))
+                keep.append(b)
+        self._batches = keep
+        return out
+
     def take_finished(self):
-        """(board_x, pi_y, v_y) of the games that have ended since the last call (won games only, utils.convert_to_train_data's
-        rows and labels); their rows leave the pending set.  None if nothing ended."""
+        """(board_x, pi_y, v_y, game id per row) of the games that have ended since the last call (won games only,
+        utils.convert_to_train_data's rows and labels); their rows leave the store.  None if nothing ended."""
         from . import utils
-        if self._pending is None:
+        if not self._new:
             return None
-        st, meta, pi = self._pending
-        j = (np.asarray(meta['game'], dtype=np.int64) - self.first_game) // self.game_stride
-        done = self.results['status'][j] != 0xFF
-        if not done.any():
+        ended = np.sort(np.concatenate(self._new))
+        self._new = []
+        st = self.results['status'][ended]
+        won = ended[(st == _lib.ST_WON_P1) | (st == _lib.ST_WON_P2)]
+        rows = self._take_rows(ended, won)
+        if not rows:
             return None
-        d = (st[done], meta[done], pi[done])
-        self._pending = (st[~done], meta[~done], pi[~done]) if (~done).any() else None
+        d = tuple(np.concatenate([x[i] for x in rows]) for i in range(3)) if len(rows) > 1 else rows[0]
         if self.keep_records:
             self._records.append(d)
         return utils.log_to_train_data(d[0], d[1], d[2], self.results, first_game=self.first_game, game_stride=self.game_stride,
@@ -361,7 +405,7 @@ class GameStore(object):
         """[(play_history, p1_reward) | (None, None)] in game-id order (the object path)"""
         assert self.keep_records
         self.take_finished()
-        rows = list(self._records) + ([self._pending] if self._pending is not None else [])
+        rows = list(self._records)
         if rows:
             st, meta, pi = (np.concatenate([x[i] for x in rows]) for i in range(3))
         else:
@@ -370,7 +414,7 @@ class GameStore(object):
 
 
 MAX_SLOTS = 4096          # concurrent games per GPU (BASELINE.json); more games than this restart in the slots that come free
-HARVEST_EVERY = 16        # plies between two harvests of the sample log
+HARVEST_EVERY = 8         # plies between two harvests of the sample log
 
 
 class SelfPlayRun(object):
@@ -409,7 +453,7 @@ class SelfPlayRun(object):
         if sink is not None:
             import queue
             import threading
-            self._queue = queue.Queue(maxsize=4)
+            self._queue = queue.Queue(maxsize=2)      # (+ the one in work: fewer than BatchSelfPlay.HOST_RING harvests alive)
             self._worker = threading.Thread(target=self._drain, daemon=True)
             self._worker.start()
 
@@ -417,12 +461,14 @@ class SelfPlayRun(object):
     def _drain(self):
         while True:
             parts = self._queue.get()
-            if parts is None:
-                return
             try:
+                if parts is None:
+                    return
                 self._absorb(parts)
-            except Exception as ex:                      # reported by the main thread at the next harvest / at finish()
+            except Exception as ex:                      # reported by the main thread at the next harvest / at flush()
                 self._worker_error.append(ex)
+            finally:
+                self._queue.task_done()
 
     def _absorb(self, parts):
         self.store.add(parts)
@@ -448,8 +494,17 @@ class SelfPlayRun(object):
         else:
             self._absorb(parts)
 
+    def drain(self):
+        """harvest what is left and wait until the worker has converted it: the store (and the sink) then hold everything
+        played so far; the run can go on afterwards"""
+        self.harvest()
+        if self._queue is not None:
+            self._queue.join()
+            if self._worker_error:
+                raise self._worker_error[0]
+
     def flush(self):
-        """harvest what is left and wait for the worker: the store (and the sink) then hold everything played so far"""
+        """drain() and retire the worker thread (end of the run)"""
         self.harvest()
         if self._queue is not None:
             self._queue.put(None)
@@ -493,16 +548,40 @@ class SelfPlayRun(object):
 
 
 class TrainDataSink(object):
-    """collects the (board_x, pi_y, v_y, game id per row) chunks of a SelfPlayRun; arrays() / save() give
-    utils.convert_to_train_data's output"""
+    """where a SelfPlayRun's finished games go, as utils.convert_to_train_data's rows (board_x, pi_y, v_y; + the game id of every
+    row).  Without a path the chunks are kept and arrays() / save() hand them over; with a path they are STREAMED into the training
+    file (utils.save_train_data's datasets board_x / pi_y / v_y, chunked along the first axis: h5lite.StreamWriter) while the run
+    goes on -- host memory stays bounded, the file is whole when close() returns."""
 
-    def __init__(self):
+    def __init__(self, path=None, chunk_rows=4096):
         self.chunks = []
         self.rows = 0
+        self.discard = False              # rows arriving are dropped (bench.py: games that ended before the timed region)
+        self.writer = None
+        if path is not None:
+            self.open(path, chunk_rows)
+
+    def open(self, path, chunk_rows=4096):
+        from .h5lite import StreamWriter
+        self.writer = StreamWriter(path, [('board_x', (7, 7, 7), '<f8'), ('pi_y', (NUM_ACTIONS,), '<f8'), ('v_y', (), '<i8')],
+                                   chunk_rows=chunk_rows)
 
     def __call__(self, board_x, pi_y, v_y, games):
-        self.chunks.append((board_x, pi_y, v_y, games))
+        if self.discard:
+            return
+        if self.writer is not None:
+            self.writer.append([board_x, pi_y, v_y])
+        else:
+            self.chunks.append((board_x, pi_y, v_y, games))
         self.rows += len(v_y)
+
+    def close(self):
+        """finish the streamed file; -> its path (None without one)"""
+        if self.writer is None:
+            return None
+        path = self.writer.close()
+        self.writer = None
+        return path
 
     def arrays(self, canonical=True, with_games=False):
         """canonical: games in id order (what convert_to_train_data(selfplay_batch(...)) gives) instead of the order they ended in"""
@@ -516,7 +595,7 @@ class TrainDataSink(object):
         return out if with_games else out[:3]
 
     def save(self, version, directory=None):
-        """utils.save_train_data (utils.py:48-56) of everything collected; the datasets are streamed chunk by chunk"""
+        """utils.save_train_data (utils.py:48-56) of everything collected"""
         from . import utils
         from .config import SAVE_TRAIN_DATA_DIR
         bx, py, vy = self.arrays()
@@ -536,11 +615,13 @@ def selfplay_batch(model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=N
 
 
 def generate_train_data(model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False, first_game=0,
-                        game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY):
+                        game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY, out_path=None):
     """utils.convert_to_train_data(selfplay_batch(...)) without a Python object per position: the finished games' rows are
     converted harvest by harvest while the GPU plays on.  -> (board_x [N,7,7,7] f64, pi_y [N,294] f64, v_y [N] int64,
-    summary dict); the same rows in the same order as utils.convert_to_train_data(generate_self_play's list)."""
-    sink = TrainDataSink()
+    summary dict); the same rows in the same order as utils.convert_to_train_data(generate_self_play's list).
+    With out_path the rows are streamed into that training file instead (datasets board_x / pi_y / v_y, games in the order they
+    ended) and (out_path, summary) is returned: host memory stays bounded whatever n_games is."""
+    sink = TrainDataSink(path=out_path)
     run = SelfPlayRun(model1, model2, n_games=n_games, sims=sims, seed=seed, randomised=randomised, first_game=first_game,
                       game_stride=game_stride, device=device, max_slots=max_slots, harvest_every=harvest_every,
                       keep_records=False, sink=sink)
@@ -549,9 +630,13 @@ def generate_train_data(model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, s
         st = run.store.results['status']
         summary = dict(games=n_games, won=int(((st == _lib.ST_WON_P1) | (st == _lib.ST_WON_P2)).sum()),
                        discarded=int(((st == _lib.ST_DISCARD_REPETITION) | (st == _lib.ST_DISCARD_NO_PROGRESS)).sum()),
-                       errors=int((st == _lib.ST_ERROR).sum()), plies=run.plies, counters=run.counters())
+                       errors=int((st == _lib.ST_ERROR).sum()), plies=run.plies, rows=sink.rows, counters=run.counters())
+        if out_path is not None:
+            return sink.close(), summary
         return sink.arrays() + (summary,)
     finally:
+        if sink.writer is not None:
+            sink.writer.abort()
         run.close()
 
 

@@ -59,10 +59,10 @@ def _build(filters=NUM_FILTERS):
 
     class BatchNorm(nn.BatchNorm2d):
         """nn.BatchNorm2d whose TRAINING statistics are taken over the rows of every rank (sync = the process group is
-        initialised and Trainer(ddp=True) switched it on): mean and biased variance of the global batch through two
-        differentiable all-reduces, the moving variance from the unbiased global one -- exactly what ONE process computes
-        on the whole batch, so N ranks with 32 / N rows each take the single-GPU step (with plain per-rank BatchNorm the
-        statistics would come from 4 rows at N = 8).  Works over RCCL and over gloo (CPU tests)."""
+        initialised and Trainer(ddp=True) switched it on): mean and biased variance of the global batch through one
+        differentiable all-reduce, the moving variance from the unbiased global one -- exactly what ONE process computes
+        on the whole batch (to float32 rounding), so N ranks with 32 / N rows each take the single-GPU step (with plain per-rank
+        BatchNorm the statistics would come from 4 rows at N = 8).  Works over RCCL and over gloo (CPU tests)."""
         sync = False
 
         def forward(self, x):
@@ -70,11 +70,17 @@ def _build(filters=NUM_FILTERS):
                 return super().forward(x)
             import torch.distributed as dist
             import torch.distributed.nn.functional as dfn
-            cnt = torch.tensor([float(x.shape[0] * x.shape[2] * x.shape[3])], dtype=x.dtype, device=x.device)
-            dist.all_reduce(cnt)
-            mean = dfn.all_reduce(x.sum(dim=(0, 2, 3))) / cnt
+            # ONE collective per layer and pass: sums of (x - m0) and (x - m0)^2 with the moving mean m0 as the common shift (the
+            # same on every rank; it keeps E[d^2] - E[d]^2 well conditioned) and the row count, all in one vector
+            c = x.shape[1]
+            d0 = x - self.running_mean.detach()[None, :, None, None]
+            cnt_local = torch.full((1,), float(x.shape[0] * x.shape[2] * x.shape[3]), dtype=x.dtype, device=x.device)
+            tot = dfn.all_reduce(torch.cat([d0.sum(dim=(0, 2, 3)), (d0 * d0).sum(dim=(0, 2, 3)), cnt_local]))
+            cnt = tot[2 * c:].detach()
+            dm = tot[:c] / cnt
+            mean = self.running_mean.detach() + dm
+            var = (tot[c:2 * c] / cnt - dm * dm).clamp_min(0.0)
             xc = x - mean[None, :, None, None]
-            var = dfn.all_reduce((xc * xc).sum(dim=(0, 2, 3))) / cnt
             with torch.no_grad():
                 m = self.momentum
                 self.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)

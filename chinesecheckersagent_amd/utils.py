@@ -73,38 +73,40 @@ def to_model_input(board, cur_player):
 def states_to_model_input(states, players):
     """to_model_input for MANY 32-byte records at once (numpy, no Python loop over positions):
     states = structured array with 'pos' [2][6] and 'last' [4] (ccsp_state), players = player to move per record.
-    -> float64 [N, 7, 7, 7], the same values as to_model_input(BoardView(record), player) row by row."""
+    -> float64 [N, 7, 7, 7], the same values as to_model_input(BoardView(record), player) row by row.
+    (Built as bytes -- the planes hold 0 .. 6 -- and widened to float64 in one pass at the end.)"""
     states = np.asarray(states)
     n = len(states)
     pos = np.asarray(states['pos'], dtype=np.int64).reshape(n, 12)
     last = np.asarray(states['last'], dtype=np.int64).reshape(n, 4)
     pl = np.asarray(players, dtype=np.int64).reshape(n)
     rows = np.arange(n)[:, None]
-    ids = np.arange(1, NUM_CHECKERS + 1, dtype=np.float64)[None, :]
-    mine = np.where((pl == PLAYER_ONE)[:, None], pos[:, :6], pos[:, 6:])
-    theirs = np.where((pl == PLAYER_ONE)[:, None], pos[:, 6:], pos[:, :6])
-    cur = np.zeros((n, BOARD_WIDTH * BOARD_HEIGHT))
-    op = np.zeros((n, BOARD_WIDTH * BOARD_HEIGHT))
+    ids = np.arange(1, NUM_CHECKERS + 1, dtype=np.uint8)[None, :]
+    one = (pl == PLAYER_ONE)[:, None]
+    mine = np.where(one, pos[:, :6], pos[:, 6:])
+    theirs = np.where(one, pos[:, 6:], pos[:, :6])
+    nc = BOARD_WIDTH * BOARD_HEIGHT
+    cur = np.zeros((n, nc), dtype=np.uint8)
+    op = np.zeros((n, nc), dtype=np.uint8)
     cur[rows, mine] = ids
     op[rows, theirs] = ids
-    out = np.zeros((n, BOARD_WIDTH * BOARD_HEIGHT, BOARD_HIST_MOVES * 2 + 1))
-    out[:, :, 0], out[:, :, 1] = cur, op
     # one ply back: the opponent's last move undone on the opponent's layer (utils.py:135-155); NO_MOVE ends the history
     m1 = last[:, 0] != NO_MOVE
     r1 = np.nonzero(m1)[0]
     op1 = op.copy()
     f, t = last[r1, 0], last[r1, 1]
     op1[r1, f], op1[r1, t] = op[r1, t], op[r1, f]
-    out[r1, :, 2], out[r1, :, 3] = cur[r1], op1[r1]
     # two plies back: the mover's own previous move undone on its layer
     m2 = m1 & (last[:, 2] != NO_MOVE)
     r2 = np.nonzero(m2)[0]
     cur2 = cur.copy()
     f, t = last[r2, 2], last[r2, 3]
     cur2[r2, f], cur2[r2, t] = cur[r2, t], cur[r2, f]
-    out[r2, :, 4], out[r2, :, 5] = cur2[r2], op1[r2]
-    out[:, :, 6] = (pl == PLAYER_TWO)[:, None]
-    return out.reshape(n, BOARD_WIDTH, BOARD_HEIGHT, BOARD_HIST_MOVES * 2 + 1)
+    z = np.zeros((n, nc), dtype=np.uint8)
+    m1c, m2c = m1[:, None], m2[:, None]
+    planes = np.stack([cur, op, np.where(m1c, cur, z), np.where(m1c, op1, z), np.where(m2c, cur2, z), np.where(m2c, op1, z),
+                       np.broadcast_to((pl == PLAYER_TWO).astype(np.uint8)[:, None], (n, nc))], axis=2)
+    return planes.astype(np.float64).reshape(n, BOARD_WIDTH, BOARD_HEIGHT, BOARD_HIST_MOVES * 2 + 1)
 
 
 def log_to_train_data(states, meta, pi, results, first_game=0, game_stride=1, randomised=False, return_games=False):

@@ -767,7 +767,19 @@ int orc_selfplay(uint64_t seed, uint64_t game, int sims, int evaluator, int rand
 
 /* fixed-work variant for the CPU baseline: `plies` MCTS plies from the position after the random
  * opening, no end-of-game rules (bench.py cpu_baseline leg).  Returns expansions performed. */
+static long bench_plies_with(uint64_t seed, uint64_t game, int sims, int evaluator, int plies, orc_eval_fn fn, void *user);
+
 long orc_bench_plies(uint64_t seed, uint64_t game, int sims, int evaluator, int plies) {
+    return bench_plies_with(seed, game, sims, evaluator, plies, NULL, NULL);
+}
+
+/* the same with an external evaluator (evaluator code 4: `fn` is called once per expansion, batch of one, as MCTS.py:93
+ * calls model.predict): the net-inclusive CPU baseline of bench.py */
+long orc_bench_plies_fn(uint64_t seed, uint64_t game, int sims, int plies, orc_eval_fn fn, void *user) {
+    return bench_plies_with(seed, game, sims, 4, plies, fn, user);
+}
+
+static long bench_plies_with(uint64_t seed, uint64_t game, int sims, int evaluator, int plies, orc_eval_fn fn, void *user) {
     board_t b; uint8_t pos12[12]; orc_initial_pos12(pos12); board_from_pos12(&b, pos12, NULL);
     int player = 1; long evals = 0; int n_plies = 0;
     for (; n_plies < INITIAL_RANDOM_MOVES; n_plies++) {
@@ -779,7 +791,7 @@ long orc_bench_plies(uint64_t seed, uint64_t game, int sims, int evaluator, int 
         board_t next; orc_search_out so;
         if (check_win(&b)) break;
         if (make_move(&b, player, seed, game, (uint32_t)n_plies, sims, i + INITIAL_RANDOM_MOVES > TOTAL_MOVES_TILL_TAU0,
-                      evaluator, NULL, NULL, &next, &so, NULL)) break;
+                      evaluator, fn, user, &next, &so, NULL)) break;
         evals += so.evals; b = next; player = 3 - player;
     }
     return evals;

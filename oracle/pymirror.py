@@ -338,15 +338,32 @@ def random_opening(seed, game, plies=6):
     return node
 
 
-def bench_plies(seed, game, sims, plies, kind=spec.EVAL_UNIFORM):
-    """`plies` searched plies of one game after the six opening plies; returns evaluator calls (= node-expansions)"""
-    model = TableEvaluator(kind)
+class NumpyNetEvaluator(object):
+    """duck-typed `model` (model.py:21-24) on the NumPy float32 restatement of the net (oracle/net_oracle.py): the evaluator of
+    BASELINE config 1 ("good_model.h5 on CPU NumPy"); batch of one per call, as MCTS.py:93 calls it"""
+
+    def __init__(self, weights):
+        import net_oracle
+        self.net, self.weights, self.calls = net_oracle, weights, 0
+
+    def predict(self, x):
+        self.calls += 1
+        logits, v = self.net.forward(self.weights, np.asarray(x, dtype=np.float32)[None], dtype=np.float32)
+        return self.net.softmax64(logits[0]), np.float32(v[0])
+
+
+def bench_plies(seed, game, sims, plies, kind=spec.EVAL_UNIFORM, model=None, t_stop=None):
+    """`plies` searched plies of one game after the six opening plies (fewer if the game ends, or once time.time() passes
+    t_stop); returns evaluator calls (= node-expansions)"""
+    import time
+    model = TableEvaluator(kind) if model is None else model
+    calls0 = model.calls
     node = random_opening(seed, game)
     for ply in range(6, 6 + plies):
-        if node.pos.winner():
+        if node.pos.winner() or (t_stop is not None and time.time() >= t_stop):
             break
-        node, _, _ = make_move(node, model, 1.0, seed, game, ply, sims)
-    return model.calls
+        node, _, _ = make_move(node, model, 1.0 if ply <= 16 else 0.01, seed, game, ply, sims)
+    return model.calls - calls0
 
 
 if __name__ == '__main__':

@@ -256,7 +256,7 @@ def test_pipelined_halves_equal_standalone_batches(golden_dir):
     for a, b_ in zip(got, want):
         assert (a[0] is None) == (b_[0] is None) and a[1] == b_[1]
         kinds.add(a[0] is None)
-        if a[0] is not None and a[0] != 'unfinished':
+        if a[0] is not None and not isinstance(a[0], str):
             assert len(a[0]) == len(b_[0])
             for (s1, p1), (s2, p2) in zip(a[0], b_[0]):
                 assert s1.pos12 == s2.pos12 and np.array_equal(p1, p2)
@@ -277,81 +277,186 @@ def test_collect_train_data_equals_object_path(golden_dir):
         games = b.run_to_completion(max_plies=600)
         bx, py, vy = b.collect_train_data()
         b.close()
-        kept = [(h, r) for h, r in games if h is not None and h != 'unfinished']
+        kept = [(h, r) for h, r in games if h is not None and not isinstance(h, str)]
         wx, wp, wv = utils.convert_to_train_data(kept)
         assert len(wx) == len(bx) > 0
         assert (np.array(wx) == bx).all() and (np.array(wp) == py).all() and list(vy) == wv
 
 
 def test_collect_refuses_a_run_with_dropped_rows(golden_dir):
-    """a sample log that is too small: the games that lost a row end in ERROR and collect() / collect_train_data()
-    raise instead of handing back histories with missing plies (their labels alternate from the first row)"""
+    """a sample log that is too small: the games that lost a row end in ERROR -- their slots stay out of play, the rest of the id
+    budget is NOT turned into ERROR games -- and collect() / collect_train_data() raise instead of handing back histories with
+    missing plies (their labels alternate from the first row); allow_errors=True hands the whole games back beside them"""
     from chinesecheckersagent_amd import _lib, selfplay as sp
     from chinesecheckersagent_amd.model import ResidualCNN
     m = ResidualCNN()
     m.load_weights(golden_dir + '/good_model.h5')
-    b = sp.BatchSelfPlay(m, n_slots=4, sims=8, seed=3, max_games=4, log_capacity=6)
-    for _ in range(9):
+    b = sp.BatchSelfPlay(m, n_slots=4, sims=8, seed=3, max_games=64, auto_restart=True, log_capacity=6)
+    for _ in range(12):
         b.play_ply()
-    assert b.eng.counters()['errors'] > 0
+    c = b.eng.counters()
+    assert 0 < c['errors'] <= 4                                  # at most one ERROR per slot: no cascade through the id budget
+    assert (b.eng.slots()['status'] == _lib.ST_ERROR).sum() == c['errors']
     with pytest.raises(_lib.CcspError, match='log'):
         b.collect()
     with pytest.raises(_lib.CcspError, match='log'):
         b.collect_train_data()
+    kinds = [g[0] for g in b.collect(allow_errors=True)]
+    assert kinds.count('error') == c['errors']
     b.close()
 
 
-def test_bench_launcher_world2_on_one_device(tmp_path):
-    """`python bench.py --gpus 2` as the driver starts it: the launcher spawns both ranks before anything touches the GPU;
-    CCSP_BENCH_ONE_DEVICE=1 puts both on cuda:0 with a gloo summary (RCCL refuses two ranks on one device).  Games shard
-    by id, so two ranks of 32 slots do exactly the work of one run of 64 slots while no game ends."""
+def _records(games):
+    """comparable form of selfplay_batch's list"""
+    out = []
+    for h, r in games:
+        if h is None or isinstance(h, str):
+            out.append((h, r))
+        else:
+            out.append(([(b.pos12, b.last4, pi.tobytes()) for b, pi in h], r))
+    return out
+
+
+def test_restarting_slots_return_the_records_of_one_slot_per_game(golden_dir, tmp_path):
+    """The delivered mode (SelfPlayRun: a few restarting slots, the log harvested every few plies and cleared, optionally two
+    half-batches, conversion in a worker thread) returns per game id EXACTLY what one slot per game returns: status, reward,
+    every searched position and pi.  Also: generate_train_data == convert_to_train_data of that list, row for row."""
+    from chinesecheckersagent_amd import _lib, selfplay as sp, utils
+    from chinesecheckersagent_amd.model import ResidualCNN
+    m = ResidualCNN()
+    m.load_weights(golden_dir + '/good_model.h5')
+    n, sims, seed, first = 22, 8, 17, 300
+    b = sp.BatchSelfPlay(m, n_slots=n, sims=sims, seed=seed, first_game=first, max_games=n, log_capacity=n * 600)
+    want = _records(b.run_to_completion(max_plies=1100))
+    b.close()
+    assert all(h != 'unfinished' for h, _ in want)
+    assert any(h is None for h, _ in want) and any(isinstance(h, list) for h, _ in want)     # both kinds of ending occur
+    for kw in (dict(max_slots=5, harvest_every=3), dict(max_slots=8, harvest_every=16, n_parts=2), dict(max_slots=64, harvest_every=7)):
+        run = sp.SelfPlayRun(m, n_games=n, sims=sims, seed=seed, first_game=first, **kw)
+        got = _records(run.run().games())
+        c = run.counters()
+        run.close()
+        assert got == want, kw
+        assert c['errors'] == 0 and c['games_won'] + c['games_discarded'] == n
+    assert _records(sp.selfplay_batch(m, n_games=n, sims=sims, seed=seed, first_game=first, max_slots=6)) == want
+    bx, py, vy, summary = sp.generate_train_data(m, n_games=n, sims=sims, seed=seed, first_game=first, max_slots=6, harvest_every=5)
+    kept = sp.selfplay_batch(m, n_games=n, sims=sims, seed=seed, first_game=first)
+    kept = [(h, r) for h, r in kept if h is not None]
+    wx, wp, wv = utils.convert_to_train_data(kept)
+    assert summary['won'] == len(kept) and summary['won'] + summary['discarded'] == n and summary['errors'] == 0
+    assert len(vy) == len(wv) > 0 and (np.array(wx) == bx).all() and (np.array(wp) == py).all() and list(vy) == wv
+    # streamed into the training file instead: the same rows (games in the order they ended)
+    from chinesecheckersagent_amd.h5lite import H5File
+    path, summary2 = sp.generate_train_data(m, n_games=n, sims=sims, seed=seed, first_game=first, max_slots=6, harvest_every=5,
+                                            out_path=str(tmp_path / 'data-for-iter-0.h5'))
+    f = H5File(path)
+    fx, fp, fv = f.get('board_x'), f.get('pi_y'), f.get('v_y')
+    assert summary2['rows'] == len(fv) == len(vy) and fv.dtype == np.int64
+    key = lambda x, p_, v: sorted(zip([a.tobytes() for a in x], [a.tobytes() for a in p_], [int(t) for t in v]))
+    assert key(fx, fp, fv) == key(bx, py, vy)
+
+
+def test_config1_one_whole_game_50_sims_matches_oracle(golden_dir):
+    """BASELINE config 1 for real (selfplay.py:155-175): ONE whole game at 50 simulations per move with good_model.h5 through
+    the delivered selfplay() on the HIP path, against the CPU oracle playing the same game id with a callback into the same
+    evaluator one position at a time: status, z, every move, every searched position and every pi bit for bit."""
+    import torch
+    from chinesecheckersagent_amd import selfplay as sp
+    from chinesecheckersagent_amd.model import ResidualCNN
+    m = ResidualCNN()
+    m.load_weights(golden_dir + '/good_model.h5')
+    assert m.backend == 'hip'
+    calls = [0]
+
+    def cb(planes_p, pos12_p, player, p_out, v_out, user):
+        x = np.ctypeslib.as_array(planes_p, shape=(343,)).astype(np.float32).reshape(1, 7, 7, 7)
+        p, v = m.evaluate_batch(torch.from_numpy(x).cuda())
+        np.ctypeslib.as_array(p_out, shape=(294,))[:] = p[0].cpu().numpy()
+        v_out[0] = float(v[0])
+        calls[0] += 1
+    fn = orc.EVAL_FN(cb)
+    seed, sims = 20261003, 50
+    seen = set()
+    for game in (0, 1, 2, 3):                                     # until a won game has been compared (a discarded one has no history)
+        o = orc.selfplay(seed, game, sims, 4, fn=fn)
+        hist, reward = sp.selfplay(m, sims=sims, seed=seed, game_id=game)
+        if o['status'] in (orc.ST_WON_P1, orc.ST_WON_P2):
+            assert reward == o['reward'] and len(hist) == len(o['pi'])
+            for k, (b, pi) in enumerate(hist):
+                assert list(b.pos12) == [int(x) for x in o['hist_pos12'][k]], 'position of searched ply %d of game %d' % (k, game)
+                assert np.array_equal(pi, o['pi'][k]), 'pi of searched ply %d of game %d differs from the oracle' % (k, game)
+            seen.add('won')
+            break
+        assert (hist, reward) == (None, None)
+        seen.add('discarded')
+    assert 'won' in seen and calls[0] > 20 * 51
+
+
+def test_generate_self_play_in_parallel_world2_on_one_device(golden_dir):
+    """train.generate_self_play_in_parallel with GPUs for workers: two rank processes (both on cuda:0 here, gloo carrying the
+    summary) started from this process play ids j mod 2; the merged list equals generate_self_play of the same ids on one
+    rank, the all-reduced summary adds up"""
+    from chinesecheckersagent_amd import selfplay as sp
+    w = golden_dir + '/good_model.h5'
+    n, sims, seed, first = 9, 8, 23, 500
+    par, summ = sp.generate_self_play_in_parallel(w, n, 2, sims=sims, seed=seed, first_game=first, devices=[0, 0], return_summary=True)
+    one = sp.generate_self_play(1, w, n, sims=sims, seed=seed, first_game=first)
+    assert _records(par) == _records(one) and len(one) > 0
+    c = summ['counters']
+    assert summ['world'] == 2 and summ['backend'] == 'gloo' and c['errors'] == 0
+    assert c['games_won'] == len(one) and c['games_won'] + c['games_discarded'] == n
+    assert sum(summ['visit_histogram']) == c['mcts_plies'] * sims
+    bx, py, vy = sp.generate_self_play_in_parallel(w, n, 2, sims=sims, seed=seed, first_game=first, devices=[0, 0], as_arrays=True)
+    assert len(vy) == sum(len(h) for h, _ in one)
+
+
+def _bench(extra, **envx):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    common = ['--sims', '24', '--steps', '3', '--warmup', '1', '--net-warmup-plies', '7', '--net-plies', '2', '--cpu-seconds', '0.5']
+    common = ['--sims', '24', '--steps', '3', '--warmup', '1', '--spread-plies', '6', '--min-seconds', '0', '--fused-plies', '3',
+              '--cpu-seconds', '0.5', '--config5-games', '6', '--config5-sims', '8']
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra + common, env=dict(env, **envx),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    return json.loads(lines[0])
 
-    def run(extra, **envx):
-        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra + common, env=dict(env, **envx),
-                           capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-        assert len(lines) == 1
-        return json.loads(lines[0])
-    two = run(['--gpus', '2', '--games', '32'], CCSP_BENCH_ONE_DEVICE='1')
-    one = run(['--gpus', '1', '--games', '64'])
+
+def test_bench_launcher_world2_on_one_device(tmp_path):
+    """`python bench.py --gpus 2` as the driver starts it: the launcher spawns both ranks before anything touches the GPU;
+    CCSP_BENCH_ONE_DEVICE=1 puts both on cuda:0 with a gloo summary (RCCL refuses two ranks on one device).  Games shard
+    by id, so two ranks of 32 slots do exactly the work of one run of 64 slots while no game ends -- in the headline (config 3
+    through SelfPlayRun) and in variant 2a; config 5 runs its N-rank loop (sharded self-play, DDP fit, sharded arena)."""
+    two = _bench(['--gpus', '2', '--games', '32'], CCSP_BENCH_ONE_DEVICE='1')
+    one = _bench(['--gpus', '1', '--games', '64'])
     assert two['n_gpus'] == 2 and one['n_gpus'] == 1
-    assert len(two['per_rank_expansions']) == 2 and sum(two['per_rank_expansions']) == round(two['value'] * two['ms_per_step'] * 3 / 1e3)
-    assert sum(two['per_rank_expansions']) == one['per_rank_expansions'][0]           # id-sharding: same games, same work
-    assert two['visit_histogram_sum'] == one['visit_histogram_sum']
     for doc in (one, two):
-        assert doc['errors'] == 0 and doc['roofline']['frac'] > 0 and doc['cpu_baseline']['value'] > 0
-        assert doc['cpu_baseline']['reference_shaped_python']['value'] > 0
-        c3 = doc['config3']
-        assert 'skipped' not in c3 and c3['errors'] == 0 and c3['node_expansions_per_s'] > 0 and c3['roofline']['bound'] == 'mfma'
-    assert sum(two['config3']['per_rank_expansions']) == one['config3']['per_rank_expansions'][0]
-    assert 'variants' in one and 'variants' not in two
+        assert doc['steps'] == 3 and doc['errors'] == 0 and doc['backend'] == 'hip' and doc['value'] > 0
+        assert doc['roofline']['bound'] == 'mfma' and 0 < doc['roofline']['frac'] < 1
+        assert doc['cpu_baseline']['value'] > 0 and doc['cpu_baseline']['kind'] == 'port' and 'PyTorch CPU module' in doc['cpu_baseline']['sample']
+        assert doc['cpu_baseline']['table_evaluator']['value'] > 0 and doc['cpu_baseline']['reference_shaped_python']['value'] > 0
+        assert doc['cpu_baseline']['config1_reference_shaped_python_numpy_net']['value'] > 0
+        v2a = doc['variants']['2a_fused_table_evaluator']
+        assert v2a['errors'] == 0 and v2a['roofline']['bound'] == 'latency/issue'
+        c5 = doc['config5']
+        assert 'failed' not in c5 and c5['selfplay_games'] == 6 * doc['n_gpus'] and c5['train_s'] > 0 and 'arena_wins' in c5
+    assert len(two['per_rank_expansions']) == 2
+    assert sum(two['per_rank_expansions']) == one['per_rank_expansions'][0]           # id-sharding: same games, same work
+    a, b = two['variants']['2a_fused_table_evaluator'], one['variants']['2a_fused_table_evaluator']
+    assert sum(a['per_rank_expansions']) == b['per_rank_expansions'][0] and a['visit_histogram_sum'] == b['visit_histogram_sum']
+    assert 'movegen_kernel' in one['variants'] and 'movegen_kernel' not in two['variants']
 
 
 def test_bench_summary_collectives_through_rccl_world1():
     """§8e: the summary collectives of the N-GPU bench (process group on the device, MAX / SUM all-reduce, all-gather, barrier)
     through RCCL itself -- a world of one rank, which is all a 1-GPU box allows (CCSP_BENCH_FORCE_DIST=1); the result must equal
     the plain 1-GPU run"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    common = ['--games', '64', '--sims', '24', '--steps', '3', '--warmup', '1', '--net-warmup-plies', '7', '--net-plies', '2', '--cpu-seconds', '0.3']
-
-    def run(**envx):
-        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + common, env=dict(env, **envx), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-        assert len(lines) == 1
-        return json.loads(lines[0])
-    a, b = run(CCSP_BENCH_FORCE_DIST='1'), run()
+    a, b = _bench(['--games', '64', '--no-config5'], CCSP_BENCH_FORCE_DIST='1'), _bench(['--games', '64', '--no-config5'])
     assert a['n_gpus'] == b['n_gpus'] == 1 and a['errors'] == 0
-    assert a['per_rank_expansions'] == b['per_rank_expansions'] and a['visit_histogram_sum'] == b['visit_histogram_sum']
-    assert a['config3']['per_rank_expansions'] == b['config3']['per_rank_expansions'] and 'skipped' not in a['config3']
+    assert a['per_rank_expansions'] == b['per_rank_expansions']
+    va, vb = a['variants']['2a_fused_table_evaluator'], b['variants']['2a_fused_table_evaluator']
+    assert va['per_rank_expansions'] == vb['per_rank_expansions'] and va['visit_histogram_sum'] == vb['visit_histogram_sum']

@@ -207,3 +207,69 @@ def test_usable_cores_and_cpu_baseline_workers():
     assert rate > 0 and games >= 2
     rate, games, dt = bench._run_cpu_workers('py', 1, 0.2, 8, 1)
     assert rate > 0 and games >= 1
+    # the net-inclusive forms: C oracle + the PyTorch CPU module, reference-shaped mirror + the NumPy float32 net
+    rate, games, dt = bench._run_cpu_workers('c_net', 1, 0.3, 8, 1)
+    assert rate > 0 and games >= 1
+    rate, games, dt = bench._run_cpu_workers('py_net', 1, 0.3, 8, 1)
+    assert rate > 0 and games >= 1
+
+
+def test_game_store_streams_the_rows_log_to_train_data_gives_at_once():
+    """selfplay.GameStore (the host side of a harvested run): rows arrive harvest by harvest from two strided parts, games end at
+    different times, some discarded; the chunks take_finished() hands out -- whatever the harvest boundaries -- add up to exactly
+    what utils.log_to_train_data makes of the whole log at once, and games() rebuilds every play_history"""
+    from chinesecheckersagent_amd import _lib, selfplay as sp, utils
+    rng = np.random.RandomState(5)
+    n_games, first, stride = 37, 1000, 3
+    length = rng.randint(1, 40, size=n_games)
+    status = rng.choice([_lib.ST_WON_P1, _lib.ST_WON_P2, _lib.ST_DISCARD_REPETITION, _lib.ST_DISCARD_NO_PROGRESS], size=n_games)
+    start = rng.randint(0, 30, size=n_games)                          # the "ply clock" at which a game starts
+    rows = []                                                         # (time, game index, ply)
+    for j in range(n_games):
+        rows += [(start[j] + k, j, 6 + k) for k in range(length[j])]
+    rows.sort()
+    end_time = start + length
+    n = len(rows)
+    st = np.zeros(n, dtype=_lib.STATE_DTYPE)
+    st['pos'] = np.argsort(rng.rand(n, 49), axis=1)[:, :12].astype(np.uint8).reshape(n, 2, 6)
+    st['last'] = 255
+    meta = np.zeros(n, dtype=_lib.META_DTYPE)
+    meta['game'] = [first + j * stride for _, j, _ in rows]
+    meta['ply'] = [p for _, _, p in rows]
+    meta['player'] = 1 + (meta['ply'] % 2)
+    pi = rng.rand(n, 294)
+    t_of = np.array([t for t, _, _ in rows])
+    full = np.zeros(n_games, dtype=_lib.RESULT_DTYPE)
+    full['status'] = status
+    full['reward'] = np.where(status == _lib.ST_WON_P1, 1, np.where(status == _lib.ST_WON_P2, -1, 0))
+    want = utils.log_to_train_data(st, meta, pi, full, first_game=first, game_stride=stride, return_games=True)
+    for every in (1, 4, 9, 100):
+        store = sp.GameStore(n_games, first, stride, False, keep_records=True)
+        got = []
+        for t0 in range(0, int(end_time.max()) + every, every):
+            sel = (t_of >= t0) & (t_of < t0 + every)
+            parts = []
+            for part in range(2):                                     # two parts: game indices part, part + 2, ... (ids strided accordingly)
+                jj = np.arange(part, n_games, 2)
+                res = np.zeros(len(jj), dtype=_lib.RESULT_DTYPE)
+                res['status'] = 0xFF
+                done = end_time[jj] <= t0 + every
+                res[done] = full[jj[done]]
+                mine = sel & (((meta['game'] - first) // stride) % 2 == part)
+                parts.append((st[mine], meta[mine], pi[mine], res, first + part * stride, stride * 2))
+            store.add(parts)
+            c = store.take_finished()
+            if c is not None:
+                got.append(c)
+        assert store.finished() and not store._batches
+        cat = [np.concatenate([c[i] for c in got]) for i in range(4)]
+        o = np.argsort(cat[3], kind='stable')
+        for a, b in zip(cat, want):
+            assert np.array_equal(a[o], b)
+        games = store.games()
+        assert len(games) == n_games
+        for j, (h, r) in enumerate(games):
+            if status[j] in (_lib.ST_WON_P1, _lib.ST_WON_P2):
+                assert r == int(full['reward'][j]) and len(h) == length[j]
+            else:
+                assert (h, r) == (None, None)

@@ -105,6 +105,35 @@ def test_h5lite_writer_roundtrip_and_h5py(tmp_path):
         assert "['board_x', 'pi_y', 'v_y'] (9, 7, 7, 7) float64 int64 1" in out
 
 
+def test_h5lite_stream_writer_chunked_files(tmp_path):
+    """h5lite.StreamWriter: rows appended piece by piece end up in CHUNKED datasets (a version-1 B-tree of raw data chunks per
+    dataset, up to three levels here) that our reader and the real HDF5 library both read back exactly -- the file the
+    self-play generator streams finished games into (selfplay.TrainDataSink(path=...))"""
+    from chinesecheckersagent_amd import h5lite
+    rng = np.random.RandomState(0)
+    conda = '/opt/conda/bin/python3.9'
+    for n, cr in ((0, 16), (5, 16), (16, 16), (1000, 16), (70000, 16), (300, 4096)):
+        path = str(tmp_path / ('s_%d_%d.h5' % (n, cr)))
+        w = h5lite.StreamWriter(path, [('board_x', (7, 7, 7), '<f8'), ('pi_y', (294,), '<f8'), ('v_y', (), '<i8')], chunk_rows=cr)
+        bx, py, vy = rng.rand(n, 7, 7, 7), rng.rand(n, 294), rng.randint(-1, 2, size=n).astype(np.int64)
+        i = 0
+        while i < n:
+            k = min(n - i, rng.randint(1, 50) if n < 5000 else rng.randint(1, 5000))
+            w.append([bx[i:i + k], py[i:i + k], vy[i:i + k]])
+            i += k
+        assert not os.path.exists(path)                  # the file appears under its name when it is whole
+        w.close()
+        f = h5lite.H5File(path)
+        assert np.array_equal(f.get('board_x'), bx) and np.array_equal(f.get('pi_y'), py) and np.array_equal(f.get('v_y'), vy)
+        if os.path.exists(conda):
+            np.savez(path + '.npz', bx=bx, py=py, vy=vy)
+            code = ("import h5py,sys,numpy as np; f=h5py.File(sys.argv[1],'r'); z=np.load(sys.argv[1]+'.npz'); "
+                    "assert f['board_x'].chunks[0]==int(sys.argv[2]); "
+                    "assert np.array_equal(np.array(f.get('board_x')),z['bx']) and np.array_equal(f['pi_y'][:],z['py']) "
+                    "and np.array_equal(f['v_y'][:],z['vy']) and f['v_y'].dtype==np.int64; print('same')")
+            assert 'same' in subprocess.check_output([conda, '-W', 'ignore', '-c', code, path, str(cr)]).decode()
+
+
 @pytest.mark.gpu
 def test_gpu_forward_matches_float64_restatement(net, golden_dir):
     import torch
