@@ -141,14 +141,14 @@ def _run_cpu_workers(kind, workers, seconds, sims, plies):
     return done / (t_end - start_at), games, t_end - start_at
 
 
-def cpu_baseline(seconds=8.0, sims=400):
+def cpu_baseline(seconds=8.0, sims=400, cores=None):
     """The oracle timed on the host cores, one process per usable core, games sharded by id (the reference's
     own multiprocessing.Pool scheme).  Top level: the C restatement (`port`) WITH THE NET as evaluator -- the product's PyTorch
     module on the CPU, float32, one position per call as MCTS.py:93 calls model.predict -- on config 3 scaled down (same 400
     simulations per move, 16 searched plies per game).  Beside it: the same with the table evaluator (config 2a's baseline), the
     reference-shaped pure-Python mirror (oracle/pymirror.py) with its calibration against the reference, and BASELINE config 1
     (one game, 50 simulations per move, good_model.h5 through the NumPy float32 net, one core)."""
-    cores = usable_cores()
+    cores = usable_cores() if not cores else min(int(cores), usable_cores())
     out = {}
     w = weights_path()
     if w:
@@ -368,7 +368,8 @@ def main():
     ap.add_argument('--no-config5', action='store_true')
     ap.add_argument('--config5-games', type=int, default=256, help='config 5: self-play games per GPU')
     ap.add_argument('--config5-sims', type=int, default=800)
-    ap.add_argument('--cpu-seconds', type=float, default=8.0)
+    ap.add_argument('--cpu-seconds', type=float, default=8.0, help='seconds per CPU-baseline leg; 0 = no CPU baseline')
+    ap.add_argument('--cpu-cores', type=int, default=0, help='cap on the worker processes of the CPU baseline (0 = every usable core)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -555,7 +556,7 @@ def main():
             if rank == 0:
                 out['config5'] = {'failed': repr(ex)}
     if rank == 0:
-        out['cpu_baseline'] = cpu_baseline(args.cpu_seconds, S) if extras_wanted else None
+        out['cpu_baseline'] = cpu_baseline(args.cpu_seconds, S, args.cpu_cores) if (extras_wanted and args.cpu_seconds > 0) else None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

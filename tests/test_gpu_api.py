@@ -417,7 +417,9 @@ def _bench(extra, **envx):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     common = ['--sims', '24', '--steps', '3', '--warmup', '1', '--spread-plies', '6', '--min-seconds', '0', '--fused-plies', '3',
-              '--cpu-seconds', '0.5', '--config5-games', '6', '--config5-sims', '8']
+              '--cpu-cores', '2', '--config5-games', '4', '--config5-sims', '8']
+    if '--cpu-seconds' not in extra:
+        common += ['--cpu-seconds', '0.4']
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra + common, env=dict(env, **envx),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -432,18 +434,19 @@ def test_bench_launcher_world2_on_one_device(tmp_path):
     by id, so two ranks of 32 slots do exactly the work of one run of 64 slots while no game ends -- in the headline (config 3
     through SelfPlayRun) and in variant 2a; config 5 runs its N-rank loop (sharded self-play, DDP fit, sharded arena)."""
     two = _bench(['--gpus', '2', '--games', '32'], CCSP_BENCH_ONE_DEVICE='1')
-    one = _bench(['--gpus', '1', '--games', '64'])
-    assert two['n_gpus'] == 2 and one['n_gpus'] == 1
+    one = _bench(['--gpus', '1', '--games', '64', '--no-config5', '--cpu-seconds', '0'])
+    assert two['n_gpus'] == 2 and one['n_gpus'] == 1 and one['cpu_baseline'] is None and 'config5' not in one
     for doc in (one, two):
         assert doc['steps'] == 3 and doc['errors'] == 0 and doc['backend'] == 'hip' and doc['value'] > 0
         assert doc['roofline']['bound'] == 'mfma' and 0 < doc['roofline']['frac'] < 1
-        assert doc['cpu_baseline']['value'] > 0 and doc['cpu_baseline']['kind'] == 'port' and 'PyTorch CPU module' in doc['cpu_baseline']['sample']
-        assert doc['cpu_baseline']['table_evaluator']['value'] > 0 and doc['cpu_baseline']['reference_shaped_python']['value'] > 0
-        assert doc['cpu_baseline']['config1_reference_shaped_python_numpy_net']['value'] > 0
         v2a = doc['variants']['2a_fused_table_evaluator']
         assert v2a['errors'] == 0 and v2a['roofline']['bound'] == 'latency/issue'
-        c5 = doc['config5']
-        assert 'failed' not in c5 and c5['selfplay_games'] == 6 * doc['n_gpus'] and c5['train_s'] > 0 and 'arena_wins' in c5
+    cb = two['cpu_baseline']
+    assert cb['value'] > 0 and cb['kind'] == 'port' and cb['cores'] <= 2 and 'PyTorch CPU module' in cb['sample']
+    assert cb['table_evaluator']['value'] > 0 and cb['reference_shaped_python']['value'] > 0
+    assert cb['config1_reference_shaped_python_numpy_net']['value'] > 0
+    c5 = two['config5']
+    assert 'failed' not in c5 and c5['selfplay_games'] == 4 * 2 and c5['train_s'] > 0 and 'arena_wins' in c5
     assert len(two['per_rank_expansions']) == 2
     assert sum(two['per_rank_expansions']) == one['per_rank_expansions'][0]           # id-sharding: same games, same work
     a, b = two['variants']['2a_fused_table_evaluator'], one['variants']['2a_fused_table_evaluator']
@@ -455,7 +458,8 @@ def test_bench_summary_collectives_through_rccl_world1():
     """§8e: the summary collectives of the N-GPU bench (process group on the device, MAX / SUM all-reduce, all-gather, barrier)
     through RCCL itself -- a world of one rank, which is all a 1-GPU box allows (CCSP_BENCH_FORCE_DIST=1); the result must equal
     the plain 1-GPU run"""
-    a, b = _bench(['--games', '64', '--no-config5'], CCSP_BENCH_FORCE_DIST='1'), _bench(['--games', '64', '--no-config5'])
+    quick = ['--games', '64', '--no-config5', '--cpu-seconds', '0']
+    a, b = _bench(quick, CCSP_BENCH_FORCE_DIST='1'), _bench(quick)
     assert a['n_gpus'] == b['n_gpus'] == 1 and a['errors'] == 0
     assert a['per_rank_expansions'] == b['per_rank_expansions']
     va, vb = a['variants']['2a_fused_table_evaluator'], b['variants']['2a_fused_table_evaluator']
