@@ -654,6 +654,11 @@ def extras(eng, G, S, torch, _lib, engine):
     v['movegen_kernel'] = {'states_per_s': n / dt, 'mean_moves': kmean, 'alg_bytes_per_state': 80 + 2 * kmean,
                            'achieved_GBps': n * (80 + 2 * kmean) / dt / 1e9, 'frac_of_hbm_peak': n * (80 + 2 * kmean) / dt / 1e9 / HBM_PEAK_GBPS,
                            'inputs': 'SURVEY 8d: Board() advanced by i mod 64 S1 plies, every third a randomised board; 2^16 distinct, tiled to 2^23'}
+    dt = t(lambda: L.ccsp_movegen_packed(sd.data_ptr(), player.data_ptr(), n, moves.data_ptr(), count.data_ptr(), masks.data_ptr(), sp_))
+    v['movegen_kernel_packed'] = {'states_per_s': n / dt, 'alg_bytes_per_state': 80 + 2 * kmean, 'achieved_GBps': n * (80 + 2 * kmean) / dt / 1e9,
+                                  'frac_of_hbm_peak': n * (80 + 2 * kmean) / dt / 1e9 / HBM_PEAK_GBPS,
+                                  'layout': 'ccsp_movegen_packed: the lists of each chunk of 32 positions back to back (whole sectors written)'}
+    moves, count, masks = rules.movegen(sd, player)              # (back to the row layout for what follows)
     mv = moves[:, 0, :].contiguous()
     nxt = torch.empty_like(sd); w = torch.zeros(n, dtype=torch.uint8, device='cuda'); pr = torch.zeros((n, 2), dtype=torch.uint8, device='cuda')
     dt = t(lambda: L.ccsp_step(sd.data_ptr(), player.data_ptr(), mv.data_ptr(), n, nxt.data_ptr(), w.data_ptr(), pr.data_ptr(), sp_))
@@ -688,8 +693,10 @@ def extras(eng, G, S, torch, _lib, engine):
     plies = c1['plies'] - c0['plies']
     try:                                          # HBM bytes per state from the committed rocprofv3 counter passes (static)
         prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))
-        for name, key in (('movegen_kernel', 'movegen_kernel<false>'), ('step_kernel', 'step_kernel'), ('encode_kernel', 'encode_kernel'),
-                          ('greedy_best_kernel', 'movegen_kernel<true>')):
+        for name, key in (('movegen_kernel', 'movegen_kernel<false>'), ('movegen_kernel_packed', 'movegen_kernel<false, true>'),
+                          ('step_kernel', 'step_kernel'), ('encode_kernel', 'encode_kernel'), ('greedy_best_kernel', 'movegen_kernel<true>')):
+            if key not in prof:
+                continue
             v[name]['hbm_bytes_per_state_counters'] = prof[key]['hbm_bytes_per_state']
             v[name]['counters_source'] = 'static: profiles/counters.json (2 x FETCH_SIZE + WRITE_SIZE, n = %d)' % prof[key]['n']
     except Exception:

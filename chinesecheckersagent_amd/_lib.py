@@ -53,6 +53,7 @@ _SIGS = {
     'ccsp_last_hip_error': (C.c_char_p, []),
     'ccsp_pack_states': (C.c_int, [_VP, _VP, C.c_int, _VP]),
     'ccsp_movegen': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
+    'ccsp_movegen_packed': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     'ccsp_step': (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     'ccsp_encode': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     'ccsp_greedy_best': (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP]),

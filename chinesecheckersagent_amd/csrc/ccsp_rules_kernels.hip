@@ -20,10 +20,19 @@ constexpr int MG_STACK = 20;                                // bytes of depth-fi
                                                             // need more is redone on the wave's one big stack (MG_BIGSTACK)
 constexpr int MG_BIGSTACK = 96;                             // >= 81 (<= 5 pending siblings per visited sub-lattice cell (16) + 1) + 6 tentative
 constexpr int MG_SLOT = 24;                                 // bytes of LDS per checker list (<= 21 used)
+#ifndef MG_LINES_STRIDE
+#define MG_LINES_STRIDE 28
+#endif
+#ifndef MG_LIST_PAD
+#define MG_LIST_PAD 0
+#endif
+
+constexpr int MG_LIST_STATE = 6 * MG_SLOT + MG_LIST_PAD;     // bytes of list staging per position
+#define LST(L, s, c, i) (L).lists[(s) * MG_LIST_STATE + (c) * MG_SLOT + (i)]
 
 struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS: 7.1 KB -> five 4-wave workgroups per CU
-    uint8_t lines[MG_CHUNK][28];                            // 27 line patterns per state (+1 pad)
-    uint8_t lists[MG_CHUNK][6][MG_SLOT];
+    uint8_t lines[MG_CHUNK][MG_LINES_STRIDE];               // 27 line patterns per state (+ pad)
+    uint8_t lists[MG_CHUNK * MG_LIST_STATE];
     uint8_t cnt[MG_CHUNK][8];
     uint8_t stack[64][MG_STACK];                            // one depth-first stack per lane
     uint8_t big[MG_BIGSTACK];
@@ -44,7 +53,10 @@ struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS
 // GREEDY (next-4): the same search, but what is written out is GreedyPlayer.decide_move(training=True)
 // (player.py:72-118): of the position's moves only those of maximum forward distance that start on the row of the
 // rear-most checker among them, into best[n][CCSP_GREEDY_MAX][2].
-template <bool GREEDY>
+// PACKED (ccsp_movegen_packed): the lists of a wave's 32 positions go out back to back in position order instead of one
+// 252-byte row each -- rows 252 bytes apart, ~67 bytes used, cost 1.27 x the algorithmic write bytes in partly written 32-byte
+// sectors (profiles/counters.json); back to back they fill whole sectors.
+template <bool GREEDY, bool PACKED = false>
 __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *__restrict__ states,
                                                              const uint8_t *__restrict__ player, int n,
                                                              uint8_t *__restrict__ moves, uint8_t *__restrict__ count,
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
             }
             // stash what the tasks need: origin cells of the side to move, in the last byte of each list slot
 #pragma unroll
-            for (int c = 0; c < 6; c++) L.lists[lane][c][MG_SLOT - 1] = (uint8_t)ccsp_sr_pos(s, (my_player - 1) * 6 + c);
+            for (int c = 0; c < 6; c++) LST(L, lane, c, MG_SLOT - 1) = (uint8_t)ccsp_sr_pos(s, (my_player - 1) * 6 + c);
         }
     }
     __syncthreads();
@@ -86,13 +98,13 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     // whole wave would step through these ~90 instructions every time one of them does.
     for (int t = lane; t < ntasks; t += 64) {
         const int s = (int)(__umul24((unsigned)t, 171u) >> 10), c = t - 6 * s;      // t / 6, exact for t < 515
-        const int x = L.lists[s][c][MG_SLOT - 1];
+        const int x = LST(L, s, c, MG_SLOT - 1);
         const int r = (int)(__umul24((unsigned)x, 37u) >> 8), col = x - 7 * r, m = r < col ? r : col;
         const uint8_t *pat = L.lines[s];
         const uint32_t p0 = pat[col], p1 = pat[7 + r], p2 = pat[20 + r - col];
         int k = 0;
 #define MG_WALK(P, POS, D, STEP) { const int np = (POS) + (D); const bool ok = (np >= 0) & (np <= 6) & ((((P) >> (np & 7)) & 1u) == 0); \
-                                   L.lists[s][c][k] = (uint8_t)(x + (STEP)); k += ok ? 1 : 0; }
+                                   LST(L, s, c, k) = (uint8_t)(x + (STEP)); k += ok ? 1 : 0; }
         MG_WALK(p0, r, -1, -7) MG_WALK(p1, col, 1, 1) MG_WALK(p2, m, 1, 8) MG_WALK(p0, r, 1, 7) MG_WALK(p1, col, -1, -1) MG_WALK(p2, m, -1, -8)
 #undef MG_WALK
         L.cnt[s][c] = (uint8_t)k;
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     auto start_task = [&](int t, uint8_t *stk) {
         st_s = (int)(__umul24((unsigned)t, 171u) >> 10);                   // t / 6, exact for t < 515 (tasks: < 192)
         st_c = t - 6 * st_s;
-        origin = L.lists[st_s][st_c][MG_SLOT - 1];
+        origin = LST(L, st_s, st_c, MG_SLOT - 1);
         cnt_n = L.cnt[st_s][st_c]; visited = 0;
         orow = (int)(__umul24((unsigned)origin, 37u) >> 8); oc = origin - 7 * orow;
         stk[0] = (uint8_t)origin; sp = 1;
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         if (c == oc) p0 &= ~(1u << orow);
         if (r == orow) p1 &= ~(1u << oc);
         if (r - c == orow - oc) p2 &= ~(1u << om);
-        L.lists[st_s][st_c][cnt_n] = (uint8_t)x;                        // a hop landing (the byte stored for the origin itself, which is
+        LST(L, st_s, st_c, cnt_n) = (uint8_t)x;                        // a hop landing (the byte stored for the origin itself, which is
         cnt_n += x != origin ? 1 : 0;                                   // not a move, is overwritten by the next landing)
         // both senses of a line in one 16-bit read: low byte = sense -, high byte = sense +
         const uint32_t h0 = *reinterpret_cast<const uint16_t *>(&T.hop[p0][r][0]);
@@ -206,18 +218,27 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
             const int s = (int)(__umul24((unsigned)t, 171u) >> 10), c = t - 6 * s;
             const int k = L.cnt[s][c];
             uint64_t m = 0;
-            for (int i = 0; i < k; i++) m |= 1ULL << L.lists[s][c][i];
+            for (int i = 0; i < k; i++) m |= 1ULL << LST(L, s, c, i);
             dest_mask[base * 6 + t] = m;
         }
         __syncthreads();                                // the counts are rewritten below
     }
     // ---- write out in the reference's move order: half a wave per position, lane = move slot ------------------
+    int my_k = 0;                                       // this position's number of moves (lane = position)
     if (lane < here) {                                  // prefix sums of the six per-checker counts, packed one byte each
         uint64_t pre = 0; int acc = 0;
 #pragma unroll
         for (int c = 0; c < 6; c++) { acc += L.cnt[lane][c]; pre |= (uint64_t)acc << (8 * (c + 1)); }
         *reinterpret_cast<uint64_t *>(L.cnt[lane]) = pre;           // cnt[s][c] now = moves of checkers < c; cnt[s][6] = K
         if (!GREEDY) count[base + lane] = (uint8_t)acc;
+        my_k = acc;
+    }
+    if (PACKED) {                                       // where each position's list starts in the chunk's stream: prefix over positions
+        const int k = my_k;
+        int incl = k;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) { const int o = __shfl_up(incl, d); if ((lane & 31) >= d) incl += o; }
+        if (lane < MG_CHUNK) reinterpret_cast<uint16_t *>(L.stack)[lane] = (uint16_t)(incl - k);      // (the stacks are free by now)
     }
     __syncthreads();
     const int half = lane >> 5, hl = lane & 31;
@@ -230,13 +251,15 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
                   p4 = (int)((pre >> 32) & 0xFF), p5 = (int)((pre >> 40) & 0xFF);
         auto move_at = [&](int j, int &id, int &dest) {
             id = (j >= p1) + (j >= p2) + (j >= p3) + (j >= p4) + (j >= p5);
-            dest = L.lists[on ? s : 0][id][j - (int)((pre >> (8 * id)) & 0xFF)];
+            dest = LST(L, on ? s : 0, id, j - (int)((pre >> (8 * id)) & 0xFF));
         };
         if (!GREEDY) {
             for (int j = hl; j < K; j += 32) {
                 int id, dest;
                 move_at(j, id, dest);
-                reinterpret_cast<uint16_t *>(moves)[(base + s) * CCSP_MAX_MOVES + j] = (uint16_t)id | ((uint16_t)dest << 8);
+                const long long row = PACKED ? base * CCSP_MAX_MOVES + reinterpret_cast<const uint16_t *>(L.stack)[on ? s : 0]
+                                             : (base + s) * CCSP_MAX_MOVES;
+                reinterpret_cast<uint16_t *>(moves)[row + j] = (uint16_t)id | ((uint16_t)dest << 8);
             }
         } else {
             // player.py:100-115 over the list in LDS: two maxima per position (half-wave reductions), then the survivors
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
                 int d = 0;
                 if (j < K) {
                     int id, dest; move_at(j, id, dest);
-                    const int sr = human_row(L.lists[s][id][MG_SLOT - 1]), er = human_row(dest);
+                    const int sr = human_row(LST(L, s, id, MG_SLOT - 1)), er = human_row(dest);
                     d = (mover == 1 ? sr - er : er - sr) + 32;
                 }
                 dbest = dbest > d ? dbest : d;
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
                 int k = 0;
                 if (j < K) {
                     int id, dest; move_at(j, id, dest);
-                    const int sr = human_row(L.lists[s][id][MG_SLOT - 1]), er = human_row(dest);
+                    const int sr = human_row(LST(L, s, id, MG_SLOT - 1)), er = human_row(dest);
                     if ((mover == 1 ? sr - er : er - sr) + 32 == dbest) k = (mover == 1 ? sr : 14 - sr) + 1;
                 }
                 kbest = kbest > k ? kbest : k;
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
                 bool keep = false; int id = 0, dest = 0;
                 if (j < K) {
                     move_at(j, id, dest);
-                    const int sr = human_row(L.lists[s][id][MG_SLOT - 1]), er = human_row(dest);
+                    const int sr = human_row(LST(L, s, id, MG_SLOT - 1)), er = human_row(dest);
                     keep = (mover == 1 ? sr - er : er - sr) + 32 == dbest && (mover == 1 ? sr : 14 - sr) + 1 == kbest;
                 }
                 const uint32_t bits = (uint32_t)(__ballot(keep) >> (32 * half));
@@ -371,6 +394,16 @@ int ccsp_movegen(const ccsp_state *s, const uint8_t *player, int n, uint8_t *mov
     if (n == 0) return CCSP_OK;
     const int grid = (n + MG_STATES - 1) / MG_STATES;
     hipLaunchKernelGGL(movegen_kernel<false>, dim3(grid), dim3(MG_THREADS), 0, (hipStream_t)stream, s, player, n, moves, count, dest_mask, g_cap);
+    CCSP_HIPCHK(hipGetLastError());
+    return CCSP_OK;
+}
+
+int ccsp_movegen_packed(const ccsp_state *s, const uint8_t *player, int n, uint8_t *moves, uint8_t *count,
+                        uint64_t *dest_mask, void *stream) {
+    if (n < 0 || (n > 0 && (!s || !player || !moves || !count))) return CCSP_EINVAL;
+    if (n == 0) return CCSP_OK;
+    const int grid = (n + MG_STATES - 1) / MG_STATES;
+    hipLaunchKernelGGL((movegen_kernel<false, true>), dim3(grid), dim3(MG_THREADS), 0, (hipStream_t)stream, s, player, n, moves, count, dest_mask, g_cap);
     CCSP_HIPCHK(hipGetLastError());
     return CCSP_OK;
 }

@@ -38,6 +38,43 @@ def movegen(states_dev, player_dev, want_masks=True):
     return moves, count, masks
 
 
+def movegen_packed(states_dev, player_dev, want_masks=True):
+    """ccsp_movegen_packed: the same lists, those of each chunk of 32 positions back to back.
+    -> (moves uint8 [n * 126, 2] (id, dest) in the packed layout, count uint8 [n], dest_mask or None); list_starts() gives the
+    entry at which every position's list begins"""
+    import torch
+    _lib.require_gpu()
+    states_dev, player_dev = _dev_u8(states_dev), _dev_u8(player_dev)
+    n = states_dev.shape[0]
+    moves = torch.zeros((n * MAX_MOVES, 2), dtype=torch.uint8, device='cuda')
+    count = torch.zeros(n, dtype=torch.uint8, device='cuda')
+    masks = torch.zeros((n, 6), dtype=torch.int64, device='cuda') if want_masks else None
+    check(_lib.lib().ccsp_movegen_packed(states_dev.data_ptr(), player_dev.data_ptr(), n, moves.data_ptr(), count.data_ptr(),
+                                         masks.data_ptr() if want_masks else None, _stream_ptr()), 'ccsp_movegen_packed')
+    return moves, count, masks
+
+
+def list_starts(count, chunk=32):
+    """entry of the packed layout at which the list of every position starts: 126 * chunk * (i // chunk) + the counts of the
+    positions before i in its chunk (count: torch tensor or array of n counts) -> int64 tensor / array [n]"""
+    import torch
+    if isinstance(count, np.ndarray):
+        c = count.astype(np.int64)
+        n = len(c)
+        pad = np.zeros((n + chunk - 1) // chunk * chunk, dtype=np.int64)
+        pad[:n] = c
+        pad = pad.reshape(-1, chunk)
+        excl = np.cumsum(pad, axis=1) - pad
+        return (excl + np.arange(pad.shape[0])[:, None] * (MAX_MOVES * chunk)).reshape(-1)[:n]
+    c = count.long()
+    n = c.shape[0]
+    pad = torch.zeros((n + chunk - 1) // chunk * chunk, dtype=torch.int64, device=c.device)
+    pad[:n] = c
+    pad = pad.view(-1, chunk)
+    excl = torch.cumsum(pad, dim=1) - pad
+    return (excl + torch.arange(pad.shape[0], device=c.device)[:, None] * (MAX_MOVES * chunk)).reshape(-1)[:n]
+
+
 def step(states_dev, player_dev, mv_dev):
     """mv uint8 [n,2] (id, dest) -> (next states uint8 [n,32], winner uint8 [n], progress uint8 [n,2])"""
     import torch

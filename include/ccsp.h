@@ -94,6 +94,14 @@ int ccsp_pack_states(const uint8_t *pos12, const uint8_t *last4, int n, ccsp_sta
 int ccsp_movegen(const ccsp_state *s, const uint8_t *player, int n,
                  uint8_t *moves, uint8_t *count, uint64_t *dest_mask, void *stream);
 
+/* The same lists in a PACKED layout: the move lists of the 32 positions of a chunk (positions 32c .. 32c + 31) stand back to
+ * back in position order, position i's list starting at entry 32 * 126 * (i / 32) + sum(count[32 * (i / 32) .. i - 1]) of
+ * `moves` (2 bytes per entry; the buffer has the same size as ccsp_movegen's, [n rounded up to 32][126][2]).  Sparse 252-byte
+ * rows cost 1.27 x the algorithmic write bytes in partly written sectors; this layout writes whole ones. */
+#define CCSP_MOVEGEN_CHUNK 32
+int ccsp_movegen_packed(const ccsp_state *s, const uint8_t *player, int n,
+                        uint8_t *moves, uint8_t *count, uint64_t *dest_mask, void *stream);
+
 /* B5-B7  Board.place (board.py:226-250) + check_win (89-111) + player_progress (254-266):
  * mv: [n][2] = (checker id, destination).  winner: [n] in {0,1,2}; progress: [n][2] of the NEW
  * state (may be NULL). */

@@ -213,3 +213,23 @@ def test_large_batch_properties(gpu):
     again_h = again.cpu().numpy().view(_lib.STATE_DTYPE).reshape(n)
     assert (again_h['occ'][has] == states['occ'][has]).all() and (again_h['pos'][has] == states['pos'][has]).all()
     assert (nxt_h['last'][has, 0] == origin[has]).all() and (nxt_h['last'][has, 1] == mv[has, 1]).all()
+
+
+def test_packed_move_lists_equal_the_rows(gpu, golden_dir):
+    """ccsp_movegen_packed (the lists of each chunk of 32 positions back to back: whole sectors instead of sparse 252-byte rows)
+    holds exactly the lists of ccsp_movegen, at rules.list_starts(count); n not a multiple of 32 and n < 32 included"""
+    import torch
+    from chinesecheckersagent_amd import _lib, rules
+    g = np.load(golden_dir + '/rules.npz')
+    pos, player = g['pos12'], g['player']
+    for n in (len(pos), 3200, 33, 31, 1):
+        sd = rules.to_device_states(_lib.pack_states(pos[:n]))
+        pl = torch.from_numpy(player[:n]).cuda()
+        mv, cnt, masks = rules.movegen(sd, pl)
+        pm, pcnt, pmasks = rules.movegen_packed(sd, pl)
+        assert torch.equal(cnt, pcnt) and torch.equal(masks, pmasks)
+        starts = rules.list_starts(pcnt)
+        mv, pm, cnt, starts = mv.cpu().numpy(), pm.cpu().numpy(), cnt.cpu().numpy(), starts.cpu().numpy()
+        assert np.array_equal(starts, rules.list_starts(cnt))
+        for i in range(n):
+            assert np.array_equal(pm[starts[i]:starts[i] + cnt[i]], mv[i, :cnt[i]]), i
