@@ -20,15 +20,27 @@ for step in "$@"; do
     tests) run tests 900 python3 -m pytest tests -m gpu -x -q ;;
     tests_all) run tests 900 python3 -m pytest tests -m gpu -q ;;
     bench) run bench 600 python3 bench.py; grep '^{' gpurun_out/${tag}_bench.log > gpurun_out/${tag}_bench.json ;;
-    stats) rm -rf /tmp/st_$tag; run stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$tag -- python3 bench.py --steps 32 --cpu-seconds 1 --net-warmup-plies 8 --net-plies 4
+    stats) rm -rf /tmp/st_$tag; run stats 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$tag -- python3 bench.py --steps 20 --warmup 5 --spread-plies 16 --fused-plies 32 --cpu-seconds 0 --no-config5
+           grep '^{' gpurun_out/${tag}_stats.log > gpurun_out/${tag}_bench_under_rocprof.json
            f=$(find /tmp/st_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${tag}_bench_kernel_stats.csv
            f=$(find /tmp/st_$tag -name "*kernel_trace.csv" | head -1)      # every launch of the multi-ply kernel with its own duration
-           [ -n "$f" ] && python3 - "$f" > gpurun_out/${tag}_fused_plies_launches.csv <<'PY'
+           [ -n "$f" ] && python3 - "$f" > gpurun_out/${tag}_launches.csv <<'PY'
 import csv, sys
 print('kernel,start_ns,duration_ms')
+net = []
 for r in csv.DictReader(open(sys.argv[1])):
     if 'fused_plies_kernel' in r['Kernel_Name']:
         print('fused_plies_kernel,%s,%.3f' % (r['Start_Timestamp'], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6))
+    if 'net_forward_kernel' in r['Kernel_Name']:
+        net.append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp']), int(r.get('Grid_Size_X') or r.get('Grid_Size') or 0)))
+# net_forward_kernel: the launches of the timed region sit in hipGraphs beside the other half-batch's tree kernels; the LAST 400
+# launches of the trace are bench.py's back-to-back burst (the figure `roofline.avg_launch_ms` reports)
+net.sort()
+big = [d for _, d, g in net if g == max(g_ for _, _, g_ in net)]
+if len(big) > 900:
+    burst, pipe = big[-400:], big[:-500]
+    print('net_forward_kernel,back_to_back_burst_last_400_avg_ms,%.6f' % (sum(burst) / len(burst) / 1e6))
+    print('net_forward_kernel,in_pipeline_%d_launches_avg_ms,%.6f' % (len(pipe), sum(pipe) / len(pipe) / 1e6))
 PY
            ;;
     pmc*) w=${step#pmc}; w=${w#:}; run pmc 1100 bash tools/pmc_round.sh $tag ${w:-all} ;;

@@ -12,8 +12,11 @@ c = json.load(open(path))
 src = ('profiles/%s (rocprofv3 --pmc, one counter set per pass with --kernel-trace only: tools/pmc_round.sh + tools/pmc_aggregate.py; '
        'FETCH_SIZE doubled per MI355X_MICROARCH.md, confirmed on step_kernel / movegen_kernel / encode_kernel whose read bytes are '
        'known exactly)' % name)
-LANES = {'movegen_kernel<false>': 2, 'movegen_kernel<true>': 2, 'step_kernel': 1, 'encode_kernel': 4}     # threads per state
-for k, x in d.items():
+LANES = {'movegen_kernel<false>': 2, 'movegen_kernel<true>': 2, 'movegen_kernel<false, true>': 2, 'step_kernel': 1, 'encode_kernel': 4}     # threads per state
+# round 3: the kernel has a second template flag (PACKED); counters.json keeps its keys: <false> = rows, <false, true> = packed, <true> = greedy
+RENAME = {'movegen_kernel<false, false>': 'movegen_kernel<false>', 'movegen_kernel<true, false>': 'movegen_kernel<true>'}
+for k, x in list(d.items()):
+    k = RENAME.get(k, k)
     if only and k not in only:
         continue
     if k in LANES:
