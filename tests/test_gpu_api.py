@@ -392,6 +392,56 @@ def test_config1_one_whole_game_50_sims_matches_oracle(golden_dir):
     assert 'won' in seen and calls[0] > 20 * 51
 
 
+def test_full_size_restarting_run_plays_the_oracles_games(golden_dir):
+    """BASELINE config 3 at FULL size in the delivered mode: 4096 restarting slots x 400 simulations with good_model.h5 through
+    SelfPlayRun exactly as bench.py runs it (two half-batches, hipGraphs, harvests every 8 plies, worker thread), until the first
+    games have ended; the TWO shortest won games are then replayed by the CPU oracle with a callback into the same evaluator, one
+    position per call: every searched position, every pi and z must agree bit for bit.  (What a whole game needs to come out right
+    at this size: 400-simulation searches on float32-net priors, the evaluator's independence of its batch slot, the end-of-ply
+    rules, the restart of a slot, the harvest and the host-side regrouping of rows by game.)"""
+    import torch
+    from chinesecheckersagent_amd import _lib, selfplay as sp
+    from chinesecheckersagent_amd.model import ResidualCNN
+    m = ResidualCNN()
+    m.load_weights(golden_dir + '/good_model.h5')
+    seed, sims, G = 20261003, 400, 4096
+    run = sp.SelfPlayRun(m, n_games=G * 4, sims=sims, seed=seed, max_slots=G, harvest_every=8)
+    try:
+        won = []
+        for _ in range(12):                                   # <= 96 plies: the first games end after ~35 searched plies
+            for _ in range(8):
+                run.play_ply()
+            st = run.store.results['status']
+            won = np.nonzero((st == _lib.ST_WON_P1) | (st == _lib.ST_WON_P2))[0]
+            if len(won) >= 8:
+                break
+        assert len(won) >= 2 and run.counters()['errors'] == 0
+        parts = run.b.parts if hasattr(run.b, 'parts') else [run.b]
+        assert all(b._graph is not None for b in parts)       # the captured-graph path really ran
+        run.store.take_finished()
+        st_, meta_, pi_ = (np.concatenate([r[i] for r in run.store._records]) for i in range(3))
+        shortest = sorted(won, key=lambda j: int(run.store.results['n_plies'][j]))[:2]
+    finally:
+        run.close()
+
+    def cb(planes_p, pos12_p, player, p_out, v_out, user):
+        x = np.ctypeslib.as_array(planes_p, shape=(343,)).astype(np.float32).reshape(1, 7, 7, 7)
+        p, v = m.evaluate_batch(torch.from_numpy(x).cuda())
+        np.ctypeslib.as_array(p_out, shape=(294,))[:] = p[0].cpu().numpy()
+        v_out[0] = float(v[0])
+    fn = orc.EVAL_FN(cb)
+    for j in shortest:
+        o = orc.selfplay(seed, int(j), sims, 4, fn=fn)
+        res = run.store.results[j]
+        assert o['status'] == int(res['status']) and o['reward'] == int(res['reward']) and len(o['plies']) == int(res['n_plies'])
+        rows = np.nonzero(meta_['game'] == j)[0]
+        rows = rows[np.argsort(meta_['ply'][rows])]
+        assert len(rows) == len(o['pi']) == int(res['n_samples'])
+        for k, r in enumerate(rows):
+            assert [int(x) for x in st_[r]['pos'].reshape(12)] == [int(x) for x in o['hist_pos12'][k]], (j, k)
+            assert np.array_equal(pi_[r], o['pi'][k]), 'pi of searched ply %d of game %d differs from the oracle at full size' % (k, j)
+
+
 def test_generate_self_play_in_parallel_world2_on_one_device(golden_dir):
     """train.generate_self_play_in_parallel with GPUs for workers: two rank processes (both on cuda:0 here, gloo carrying the
     summary) started from this process play ids j mod 2; the merged list equals generate_self_play of the same ids on one
