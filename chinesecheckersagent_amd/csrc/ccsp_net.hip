@@ -44,9 +44,6 @@ constexpr int NPOL = 294, NPOL_PAD = 304;
 #ifndef CCSP_NET_PDG
 #define CCSP_NET_PDG 1                   // policy dense: groups of four k the weight loads run ahead
 #endif
-#ifndef CCSP_NET_SHAPE
-#define CCSP_NET_SHAPE 8                 // default workgroup shape of ccsp_net_forward (see Cfg)
-#endif
 
 // ---- packed weight blob layout (floats) ----------------------------------------------------------------
 struct Layout {
@@ -97,6 +94,8 @@ template <int NBv, int NWv>
 struct Cfg {
     static constexpr int NB = NBv, NW = NWv, NTH = NWv * 64, ROWS = NBv * 25, MT = (NBv * 25 + 15) / 16;
     static constexpr int NSPLIT = NWv / 2;                       // waves sharing the k-range of tile MT - 1 of a 32-column layer
+    static constexpr int NSEG = 4;                               // k-segments every output of a 3x3 layer is summed from (gemm_tiles_split): the
+                                                                 // SAME in every shape, so that both shapes compute a position with the same bits
     static constexpr int PADROWS = PAD0 + NBv * PADPOS + 1;
     static constexpr int INROWS = NBv * 49 + 56;                 // staged input planes + what padding rows / the zero-weight 10th tap reach
     static constexpr int NTW = (19 + NWv - 1) / NWv;             // policy dense: column tiles per wave
@@ -109,7 +108,7 @@ struct Smem {
     float y1[C::PADROWS * LDY];          // 32-channel 1x1 output = 3x3 input, zero halo; the stem's input planes and the policy
                                          // conv output alias it
     float y2[C::MT * 16 * LDY];          // 32-channel 3x3 output; logits / value scratch alias it
-    float part[2][C::NSPLIT][256];       // partial sums of the k-split last row tile of the 32-column layers
+    float part[2][C::NSEG][256];         // partial sums (one per k-segment) of the k-split last row tile of the 3x3 layers
     static_assert(C::INROWS * LDI <= C::PADROWS * LDY, "the staged input planes alias y1");
     static_assert(C::MT * 16 * 16 <= C::PADROWS * LDY, "the policy conv output aliases y1");
     static_assert(256 + C::NB * (NPOL_PAD + 32) <= C::MT * 16 * LDY, "logits and value scratch alias y2");
@@ -193,21 +192,24 @@ __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, in
 // 32 slots duplicated, four phantom), a wave takes THREE full row tiles of its column tile and a quarter of the
 // k-range of row tile 12 (xmt) of the same column tile -- same weight stream, 3.25 jobs' worth of MFMAs instead of
 // 4.  The quarter's raw sums go to Smem::part and are added up in a fixed order after the layer's barrier.
-// EVERY output of these layers -- full tiles too -- is the fixed-order sum ((c0 + c1) + c2) + c3 of NSPLIT accumulation chains
-// over the NSPLIT segments of the k-range, so that a row's arithmetic does not depend on which tile (hence which slot of the
+// EVERY output of these layers -- full tiles too -- is the fixed-order sum ((c0 + c1) + c2) + c3 of NSEG = 4 accumulation chains
+// over four segments of the k-range (in every workgroup shape: the NSH waves that share the last tile take NSEG / NSH segments each), so that a row's arithmetic does not depend on which tile (hence which slot of the
 // batch) it sits in: an evaluation is a function of the position alone, whatever the batch size, the slot or the sharding.
-template <int NMT, int KB, int NSPLIT, typename AFrag, typename Next, typename Epi>
+template <int NMT, int KB, int NSEG, int NSH, typename AFrag, typename Next, typename Epi>
 __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart, f32x4 (&pre)[NPREMAX],
-                                                 AFrag afrag, Next next, Epi epi, float *part /* [256] of this (nt, kpart) */) {
+                                                 AFrag afrag, Next next, Epi epi, float *part /* [NSEG][256] of this nt */) {
     constexpr int NPRE = Pre<KB>::N;
     constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;
+    constexpr int SPW = NSEG / NSH;                                     // segments of the shared tile that one of its NSH waves computes
+    static_assert(NSEG % NSH == 0, "the waves sharing the last tile take whole segments");
     const int lane = threadIdx.x & 63;
-    const int kb0 = (KB * kpart) / NSPLIT, kb1 = (KB * (kpart + 1)) / NSPLIT;
-    f32x4 acc[NMT][NSPLIT], accx = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NMT][NSEG], accx[SPW];
 #pragma unroll
     for (int i = 0; i < NMT; i++)
 #pragma unroll
-        for (int c = 0; c < NSPLIT; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < NSEG; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < SPW; c++) accx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int w0 = wbase + nt * KB * 256;
     f32x4 bq[PB];
 #pragma unroll
@@ -220,7 +222,7 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
     for (int kb = 0; kb < KB; kb++) {
         int seg = 0;                                                    // the segment k-block kb belongs to (static after unrolling)
 #pragma unroll
-        for (int c = 1; c < NSPLIT; c++) seg += kb >= (KB * c) / NSPLIT ? 1 : 0;
+        for (int c = 1; c < NSEG; c++) seg += kb >= (KB * c) / NSEG ? 1 : 0;
         if (kb + 1 < KB) {
 #pragma unroll
             for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
@@ -234,9 +236,10 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
             for (int i = 0; i < NMT; i++)
                 acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
         }
-        if ((kb >= kb0) & (kb < kb1)) {                                 // wave-uniform: ONE scalar branch per k-block
+        if (seg / SPW == kpart) {                                       // wave-uniform: ONE scalar branch per k-block
 #pragma unroll
-            for (int j = 0; j < 4; j++) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], accx, 0, 0, 0);
+            for (int j = 0; j < 4; j++)
+                accx[seg % SPW] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], accx[seg % SPW], 0, 0, 0);
         }
     }
     next();
@@ -244,10 +247,12 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
     for (int i = 0; i < NMT; i++) {
         f32x4 sum = acc[i][0];
 #pragma unroll
-        for (int c = 1; c < NSPLIT; c++) sum = sum + acc[i][c];          // the order in which the shared tile's partial sums are added up by its consumer
+        for (int c = 1; c < NSEG; c++) sum = sum + acc[i][c];            // the order in which the shared tile's partial sums are added up by its consumer
         epi(mt0 + i, sum, i);
     }
-    *reinterpret_cast<f32x4 *>(&part[lane * 4]) = accx;                 // D-fragment order: [lane][reg]
+#pragma unroll
+    for (int c = 0; c < SPW; c++)
+        *reinterpret_cast<f32x4 *>(&part[(kpart * SPW + c) * 256 + lane * 4]) = accx[c];      // D-fragment order: [segment][lane][reg]
 }
 
 // The same share-out for the SHORT 32-column layers (the blocks' first 1x1, K = 64): there a reduction pass and its two
@@ -449,8 +454,8 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             auto epi = [&](int mt, const f32x4 &acc, int i) {
                 *reinterpret_cast<f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + nt2 * 16 + 4 * q]) = relu4(acc + bv);
             };
-            gemm_tiles_split<3, 18, NSPLIT>(wb, LAY.l2_w[blk], nt2, mt3, MT - 1, qr, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
-                                    S.part[nt2][qr]);
+            gemm_tiles_split<3, 18, C::NSEG, NSPLIT>(wb, LAY.l2_w[blk], nt2, mt3, MT - 1, qr, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
+                                                     &S.part[nt2][0][0]);
             NET_STAMP(32 + blk);                             // diagnostic: wave 0 done with its share of the 3x3 layer
 #ifdef CCSP_STAMPS
             if (blockIdx.x == 0 && lane == 0 && blk == 4) {
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 for (int kb = 0; kb < 2; kb++) {
                     f32x4 v = *reinterpret_cast<const f32x4 *>(&S.part[kb][0][lane * 4]);
 #pragma unroll
-                    for (int c = 1; c < NSPLIT; c++) v = v + *reinterpret_cast<const f32x4 *>(&S.part[kb][c][lane * 4]);
+                    for (int c = 1; c < C::NSEG; c++) v = v + *reinterpret_cast<const f32x4 *>(&S.part[kb][c][lane * 4]);
                     ax[kb] = relu4(v + bias4(LAY.l2_b[blk] + kb * 16));
                 }
             }
@@ -675,7 +680,10 @@ static int launch_net(const float *packed, const float *planes, int n, float *lo
     return CCSP_OK;
 }
 
-static int g_net_shape = CCSP_NET_SHAPE;      // positions per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
+static int g_net_shape = 0;                   // positions per workgroup: 8 (one workgroup per CU), 4 (two per CU), 0 = by batch size
+#ifndef CCSP_NET_SMALL
+#define CCSP_NET_SMALL 1024                   // batches up to this many positions run in the <4, 4> shape (see ccsp_net_forward)
+#endif
 
 extern "C" {
 
@@ -733,7 +741,7 @@ int ccsp_net_pack(const float *plain, float *packed) {
 // Test / measurement hook: pick the workgroup shape of ccsp_net_forward (8 or 4 positions per workgroup; anything else
 // restores the default).  Both shapes compute every position with the same arithmetic in the same order: results are identical.
 int ccsp_debug_net_shape(int positions_per_workgroup) {
-    g_net_shape = (positions_per_workgroup == 4 || positions_per_workgroup == 8) ? positions_per_workgroup : CCSP_NET_SHAPE;
+    g_net_shape = (positions_per_workgroup == 4 || positions_per_workgroup == 8) ? positions_per_workgroup : 0;
     return g_net_shape;
 }
 
@@ -741,7 +749,12 @@ int ccsp_net_forward(const float *packed, const float *planes, int n, float *log
     if (n < 0 || (n > 0 && (!packed || !planes || !v))) return CCSP_EINVAL;
     if (n == 0) return CCSP_OK;
     static bool attr8[64] = {false}, attr4[64] = {false};
-    if (g_net_shape == 4) return launch_net<Cfg<4, 4>>(packed, planes, n, logits, p, v, stream, attr4);
+    // Both shapes compute a position with the same arithmetic in the same order (bit-identical results), so the choice is one of speed
+    // only: a workgroup of <4, 4> carries 4 positions on 4 waves in about half the time a workgroup of <8, 8> carries 8 on 8, which is what
+    // counts while the batch does not fill the 256 CUs anyway (the arena's 24 games, one game of selfplay(), config 5's small cohorts):
+    // the launch is as long as ONE workgroup.  Large batches want <8, 8>: the policy dense layer's weights cross L2 once per 8 positions.
+    const int shape = g_net_shape ? g_net_shape : (n <= CCSP_NET_SMALL ? 4 : 8);
+    if (shape == 4) return launch_net<Cfg<4, 4>>(packed, planes, n, logits, p, v, stream, attr4);
     return launch_net<Cfg<8, 8>>(packed, planes, n, logits, p, v, stream, attr8);
 }
 

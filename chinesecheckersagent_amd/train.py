@@ -226,9 +226,46 @@ class Trainer(object):
         self.opt.step()
         return float(total.detach()), float(policy.detach()), float(value.detach()), float(reg.detach())
 
-    def fit(self, board_x, pi_y, v_y, batch_size=BATCH_SIZE, epochs=EPOCHS, validation_split=0.05, seed=0):
+    def _capture_step(self, batch_size):
+        """One optimisation step on a full batch -- forward, the three loss terms, backward, the SGD update: some four hundred small
+        kernels -- captured ONCE as a hipGraph on static input tensors and replayed per batch: the step of this 250 k-parameter net is
+        launch-bound in eager mode (8 ms; the GPU work itself is well under 2).  Lazy initialisation (convolution algorithm choice,
+        the optimiser's momentum buffers) is driven by three throw-away steps whose effect is undone before the capture: parameters
+        and BatchNorm statistics are put back, the momentum buffers zeroed (SGD's first step from a zero buffer = its first step)."""
+        torch = self.torch
+        dev = self.device
+        self._gx = torch.zeros((batch_size, 7, 7, 7), dtype=torch.float32, device=dev)
+        self._gpi = torch.full((batch_size, NUM_ACTIONS), 1.0 / NUM_ACTIONS, dtype=torch.float32, device=dev)
+        self._gz = torch.zeros(batch_size, dtype=torch.float32, device=dev)
+        keep = {k: v.clone() for k, v in self.net.state_dict().items()}
+        had_state = len(self.opt.state) > 0
+        opt_keep = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.opt.state.items()} if had_state else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self.step(self._gx, self._gpi, self._gz)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            self.net.load_state_dict(keep)
+            for p_, st in self.opt.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(opt_keep[id(p_)][k]) if had_state else v.zero_()
+        self.net.train()
+        g = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            logits, v = self.net(self._gx)
+            total, policy, value, reg = self.loss(logits, v, self._gpi, self._gz)
+            total.backward()
+            self.opt.step()
+        self._graph, self._graph_loss, self._graph_bs = g, total, batch_size
+
+    def fit(self, board_x, pi_y, v_y, batch_size=BATCH_SIZE, epochs=EPOCHS, validation_split=0.05, seed=0, use_graph=True):
         """keras fit semantics: the LAST validation_split of the arrays is held out (before shuffling), the
-        rest is reshuffled every epoch; returns per-epoch (train loss, val loss)"""
+        rest is reshuffled every epoch; returns per-epoch (train loss, val loss).  On one GPU the full batches are replays of a
+        captured hipGraph of the step (_capture_step); a ragged last batch, DistributedDataParallel and the CPU run eagerly."""
         torch = self.torch
         x = torch.as_tensor(np.asarray(board_x), dtype=torch.float32)
         pi = torch.as_tensor(np.asarray(pi_y), dtype=torch.float32)
@@ -239,11 +276,30 @@ class Trainer(object):
         xv, pv, zv = x[split:].to(self.device), pi[split:].to(self.device), z[split:].to(self.device)
         gen = torch.Generator().manual_seed(seed)
         hist = []
+        graph = None
+        if use_graph and self.ddp is None and self.device.type == 'cuda' and split >= batch_size:
+            try:
+                if getattr(self, '_graph', None) is None or self._graph_bs != batch_size:
+                    self._capture_step(batch_size)
+                graph = self._graph
+            except Exception as ex:
+                from .selfplay import _strict, _warn
+                self._graph = None
+                if _strict():
+                    raise
+                _warn('hipGraph capture of the training step failed (%r): eager steps' % (ex,))
         for _ in range(epochs):
             perm = torch.randperm(split, generator=gen).to(self.device)
             tot, cnt = 0.0, 0
+            tot_dev = torch.zeros((), dtype=torch.float64, device=self.device) if graph is not None else None
             for i in range(0, split, batch_size):
                 idx = perm[i:i + batch_size]
+                if graph is not None and len(idx) == batch_size:
+                    self._gx.copy_(xt[idx]); self._gpi.copy_(pt[idx]); self._gz.copy_(zt[idx])
+                    graph.replay()
+                    tot_dev += self._graph_loss.detach().double() * batch_size        # (no host read-back inside the epoch)
+                    cnt += batch_size
+                    continue
                 if self.ddp is not None:
                     # every rank draws the SAME permutation (same seed) and takes its own share of each global batch (rows
                     # rank, rank + world, ...: shares differ by at most one row and step() weights them, so the averaged
@@ -263,6 +319,8 @@ class Trainer(object):
                 self.net.eval()
                 with torch.no_grad():
                     val = float(self.loss(*self.net(xv), pv, zv)[0])
+            if tot_dev is not None:
+                tot += float(tot_dev)
             hist.append((tot / max(cnt, 1), val))
         return hist
 

@@ -254,7 +254,8 @@ int ccsp_net_pack(const float *plain, float *packed);
 int ccsp_net_forward(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream);
 
 /* test / measurement hook: workgroup shape of ccsp_net_forward -- 8 positions per workgroup (one workgroup per CU) or 4 (two per
- * CU); other values restore the default.  Same results either way.  Returns the value in force. */
+ * CU); any other value restores the default: by batch size (small batches, which cannot fill the GPU, run in the shape whose single
+ * workgroup is done sooner).  Bit-identical results in both shapes.  Returns the value in force (0 = by batch size). */
 int ccsp_debug_net_shape(int positions_per_workgroup);
 
 /* ---- read-back (synchronous; host buffers unless said otherwise) ----------------------------------- */

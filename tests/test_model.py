@@ -229,10 +229,10 @@ def test_gpu_evaluation_is_a_function_of_the_position_alone(net, golden_dir):
     base = torch.from_numpy(net['planes'][:3].astype(np.float32)).cuda()
     ref64 = net['logits_good_model'][:3]
     try:
-        for shape in (8, 4):
+        want = None                                    # ONE expectation for every shape: the shapes agree bit for bit, too
+        for shape in (8, 4, 0):                        # 0 = chosen by batch size: <4,4> up to 1024 positions, <8,8> beyond
             assert L.ccsp_debug_net_shape(shape) == shape
-            want = None
-            for n in (3, 16, 19, 51):
+            for n in (3, 16, 19, 51) + ((1024, 1027) if shape == 0 else ()):
                 idx = torch.arange(n, device='cuda') % 3
                 lg, v = m.predict_batch(base[idx].contiguous())
                 p, _ = m.evaluate_batch(base[idx].contiguous())
