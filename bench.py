@@ -317,6 +317,31 @@ def config2a(args, torch, rank, world, local, barrier, engine, _lib):
     return eng, d, elapsed, kernel_ms, launches, plies
 
 
+def config1(args, torch, local):
+    """BASELINE configs[0] on the GPU: ONE game at a time at 50 simulations per move with good_model.h5 through the delivered
+    selfplay() -- a batch of one position per evaluator launch, so everything here is latency: seconds per whole game (engine set-up
+    and graph capture of every call included) beside the CPU's figure for the same configuration (cpu_baseline.config1_...)"""
+    from chinesecheckersagent_amd import selfplay as sp
+    from chinesecheckersagent_amd.model import ResidualCNN
+    model = ResidualCNN(device='cuda:%d' % local)
+    model.load_weights(weights_path())
+    sp.selfplay(model, sims=50, seed=SEED, game_id=10 ** 6)          # (first call: library and allocator warm-up)
+    torch.cuda.synchronize()
+    games, plies, won = 6, 0, 0
+    t0 = time.time()
+    for g in range(games):
+        hist, reward = sp.selfplay(model, sims=50, seed=SEED, game_id=g)
+        if hist is not None:
+            won += 1
+            plies += len(hist)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    return dict(workload='config 1: one game at a time (a single slot: one position per evaluator launch), 50 sims/move, %s, '
+                         'selfplay() called %d times in a row' % (os.path.basename(weights_path()), games),
+                games=games, games_won=won, seconds_per_game=dt / games, games_per_s=games / dt,
+                searched_plies_of_won_games=plies)
+
+
 def config5(args, torch, rank, world, local, dist):
     """BASELINE configs[4] in miniature through train.evolve: self-play at 800 simulations per move -> convert / augment / save
     -> fit -> 24-game arena; wall seconds per phase.  With N ranks: sharded self-play and arena, DDP fit (train.evolve(dist=...))."""
@@ -540,6 +565,8 @@ def main():
                 raise SystemExit('config 2a counted %d engine errors' % tot['errors'])
         if world == 1:
             out['variants'].update(extras(eng, G, S, torch, _lib, engine))
+            if weights_path():
+                out['config1'] = config1(args, torch, local)
         eng.close()
 
     # ---- config 5 in miniature: every rank --------------------------------------------------------------------------------

@@ -491,6 +491,7 @@ def test_bench_launcher_world2_on_one_device(tmp_path):
         assert doc['roofline']['bound'] == 'mfma' and 0 < doc['roofline']['frac'] < 1
         v2a = doc['variants']['2a_fused_table_evaluator']
         assert v2a['errors'] == 0 and v2a['roofline']['bound'] == 'latency/issue'
+    assert one['config1']['games'] == 6 and one['config1']['seconds_per_game'] > 0 and 'config1' not in two
     cb = two['cpu_baseline']
     assert cb['value'] > 0 and cb['kind'] == 'port' and cb['cores'] <= 2 and 'PyTorch CPU module' in cb['sample']
     assert cb['table_evaluator']['value'] > 0 and cb['reference_shaped_python']['value'] > 0
