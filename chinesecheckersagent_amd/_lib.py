@@ -17,7 +17,7 @@ OK, EINVAL, ENOMEM, EHIP, ENODEVICE, ESTATE = 0, -1, -2, -3, -4, -5
 ST_RUNNING, ST_WON_P1, ST_WON_P2, ST_DISCARD_REPETITION, ST_DISCARD_NO_PROGRESS, ST_ERROR, ST_IDLE = range(7)
 EVAL_UNIFORM, EVAL_HASH, EVAL_FORWARD, EVAL_ROLLOUT, EVAL_EXTERNAL = range(5)
 MODE_SELFPLAY, MODE_ARENA, MODE_GREEDY_DATA = range(3)
-GREEDY_P1, GREEDY_P2, GREEDY_ALTERNATE, GREEDY_RANDOM_START = 1, 2, 4, 8
+GREEDY_P1, GREEDY_P2, GREEDY_ALTERNATE, GREEDY_RANDOM_START, GREEDY_STOCHASTIC_P1, GREEDY_STOCHASTIC_P2 = 1, 2, 4, 8, 16, 32
 GREEDY_MAX = 32
 (CNT_EXPANSIONS, CNT_TERMINAL_SIMS, CNT_SIMS, CNT_PLIES, CNT_MCTS_PLIES, CNT_GAMES_WON, CNT_GAMES_DISCARDED,
  CNT_SUM_DEPTH, CNT_SUM_CHILDREN, CNT_SELECT_EDGES, CNT_SAMPLES, CNT_ERRORS) = range(12)

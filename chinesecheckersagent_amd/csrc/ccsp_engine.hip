@@ -780,6 +780,12 @@ __device__ __forceinline__ bool greedy_to_move(const Params &P, const Slot &sl) 
     if ((P.greedy & CCSP_GREEDY_ALTERNATE) && (sl.game & 1)) seats = ((seats & 1u) << 1) | (seats >> 1);   // ai_vs_greedy.py:47-48
     return ((seats >> (sl.player - 1)) & 1u) != 0;
 }
+// is the GreedyPlayer to move the stochastic variant (player.py:68, stochastic=True)?
+__device__ __forceinline__ bool stochastic_to_move(const Params &P, const Slot &sl) {
+    uint32_t seats = ((uint32_t)P.greedy >> 4) & 3u;
+    if ((P.greedy & CCSP_GREEDY_ALTERNATE) && (sl.game & 1)) seats = ((seats & 1u) << 1) | (seats >> 1);
+    return ((seats >> (sl.player - 1)) & 1u) != 0;
+}
 // no search this ply: a random opening ply or a GreedyPlayer's move
 __device__ __forceinline__ bool no_search(const Params &P, const Slot &sl) { return sl.opening_left > 0 || greedy_to_move(P, sl); }
 
@@ -817,6 +823,49 @@ __device__ __forceinline__ int wave_greedy_best(const Lds &lds, const ccsp_sr &s
     return ccsp_popc64(f_lo) + ccsp_popc64(f_hi);
 }
 
+// GreedyPlayer(stochastic=True).decide_move (player.py:77-97) on the move list wave_movegen left in LDS (K entries): the moves that
+// go forward are drawn with probability dist / sum(dist) -- float64 priors, cumulative sums in list order, the first one whose
+// cdf / cdf[last] exceeds u (np.random.choice(len, p=prior) through spec.sample_index) -- or, if none goes forward, one of all the
+// moves uniformly (random.choice(backward_moves), player.py:92).  Returns the list position of the move.  The cumulative sums are a
+// serial float64 chain in list order (lane 0, once per ply of such a seat).
+__device__ __forceinline__ int wave_greedy_stochastic(Lds &lds, const ccsp_sr &st, int player, int K, uint64_t u64) {
+    const int lane = lane_id();
+    __syncthreads();
+    int nf = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int j = lane + 64 * h;
+        int d = 0;
+        if (j < K) {
+            int id, dest;
+            move_of(lds, j, id, dest);
+            const int s = human_row(ccsp_sr_pos(st, (player - 1) * 6 + id)), e = human_row(dest);
+            d = player == 1 ? s - e : e - s;                             // player.py:83-85
+        }
+        lds.gam[j] = d > 0 ? (double)d : 0.0;                            // forward moves carry their distance, the others 0
+        nf += ccsp_popc64(__ballot(d > 0));
+    }
+    __syncthreads();
+    if (nf == 0) return (int)ccsp_choice(u64, (uint32_t)K);              // every move is a "backward" move, in list order
+    if (lane == 0) {
+        double sum = 0.0;
+        for (int j = 0; j < K; j++) sum = sum + lds.gam[j];              // integers: exact
+        double last = 0.0;
+        for (int j = 0; j < K; j++) if (lds.gam[j] > 0.0) last = last + lds.gam[j] / sum;
+        const double u = (double)(u64 >> 11) * 1.1102230246251565e-16;
+        double c = 0.0; int pick = -1, lastf = 0;
+        for (int j = 0; j < K; j++) {
+            if (!(lds.gam[j] > 0.0)) continue;
+            lastf = j;
+            c = c + lds.gam[j] / sum;
+            if (c / last > u) { pick = j; break; }
+        }
+        lds.cnt[6] = (uint8_t)(pick >= 0 ? pick : lastf);
+    }
+    __syncthreads();
+    return (int)lds.cnt[6];
+}
+
 // GreedyDataGenerator.generate_play after a greedy ply (data_generators.py:57-69)
 __device__ __forceinline__ void slot_after_move_gen(const Params &P, Lds &lds, Slot &sl, int id, int dest, Tally &tl) {
     const ccsp_sr ns = ccsp_place(sl.st, (int)sl.player, id, dest);
@@ -843,6 +892,13 @@ __device__ __forceinline__ void slot_after_move_gen(const Params &P, Lds &lds, S
 __device__ __forceinline__ void wave_greedy_ply(const Params &P, Lds &lds, Slot &sl, Tally &tl) {
     const int lane = lane_id();
     const int K = wave_movegen(lds, sl.st, (int)sl.player);
+    if (!P.gen && K > 0 && stochastic_to_move(P, sl)) {                 // Game.start's seat with GreedyPlayer(stochastic=True)
+        const int j = wave_greedy_stochastic(lds, sl.st, (int)sl.player, K, ccsp_rng_from(sl.hgame, sl.ply, 0, 0, CCSP_P_GREEDY));
+        int id, dest;
+        move_of(lds, j, id, dest);
+        slot_after_move_arena(P, lds, sl, id, dest, tl);
+        return;
+    }
     uint64_t f_lo, f_hi;
     const int cnt = K > 0 ? wave_greedy_best(lds, sl.st, (int)sl.player, K, f_lo, f_hi) : 0;
     if (cnt == 0) { sl.status = CCSP_ST_ERROR; tl.errors += 1; return; }
@@ -1467,7 +1523,7 @@ ccsp_ctx *ccsp_create(const ccsp_config *cfg, int *err) {
 static ccsp_ctx *create_on_device(const ccsp_config *cfg, int *err) {
     if (err) *err = CCSP_OK;
     if (!cfg || cfg->n_slots <= 0 || cfg->sims <= 0 || cfg->sims > 4000 || cfg->game_stride == 0 || cfg->max_games == 0 ||
-        cfg->mode < CCSP_MODE_SELFPLAY || cfg->mode > CCSP_MODE_GREEDY_DATA || cfg->greedy < 0 || cfg->greedy > 15 || cfg->stuck_limit < 0 ||
+        cfg->mode < CCSP_MODE_SELFPLAY || cfg->mode > CCSP_MODE_GREEDY_DATA || cfg->greedy < 0 || cfg->greedy > 63 || cfg->stuck_limit < 0 ||
         (cfg->mode == CCSP_MODE_SELFPLAY && cfg->greedy != 0)) {
         if (err) *err = CCSP_EINVAL;
         return nullptr;

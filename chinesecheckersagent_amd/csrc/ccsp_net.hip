@@ -346,6 +346,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     wb.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W), 0, LAY.total * 4, 0x00020000);
     wb.voff = lane * 16;
 
+#ifdef CCSP_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) net_stamps[62] = __builtin_amdgcn_s_memtime();
+#endif
     // ---- input planes -> LDS [INROWS][LDI] (channels 7.. and the cells past the 8 positions = 0), aliasing y1 ----------
     float *in = S.y1;
     for (int i = tid; i < INROWS * LDI; i += NTH) {

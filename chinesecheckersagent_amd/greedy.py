@@ -75,11 +75,14 @@ class GreedyDataGenerator(object):
         return generate_greedy_games(n, self.randomised, self.random_start, first_game=first, stuck_limit=self.stuck_limit)
 
 
-def greedy_vs_greedy(num_games, enforce_move_limit=False, seed=None, first_game=0):
-    """Game(p1_type='greedy', p2_type='greedy').start() num_games times (greedy_vs_greedy.py): -> {1: wins, 2: wins, None: draws}"""
+def greedy_vs_greedy(num_games, enforce_move_limit=False, seed=None, first_game=0, stochastic=(False, False)):
+    """Game(p1_type='greedy', p2_type='greedy').start() num_games times (greedy_vs_greedy.py): -> {1: wins, 2: wins, None: draws}.
+    stochastic = (player one, player two): that seat is GreedyPlayer(stochastic=True) (player.py:77-97) -- game.py:105-119's
+    deterministic-against-stochastic statistics are greedy_vs_greedy(10000, stochastic=(False, True))."""
+    bits = _lib.GREEDY_P1 | _lib.GREEDY_P2 | (_lib.GREEDY_STOCHASTIC_P1 if stochastic[0] else 0) | (_lib.GREEDY_STOCHASTIC_P2 if stochastic[1] else 0)
     e = SelfPlayEngine(n_slots=num_games, sims=1, seed=_default_seed[0] if seed is None else seed, first_game=first_game,
                        max_games=num_games, log_capacity=1, arena=True, enforce_move_limit=enforce_move_limit,
-                       greedy=_lib.GREEDY_P1 | _lib.GREEDY_P2)
+                       greedy=bits)
     try:
         for _ in range(256):
             e.play_plies(0, 32)

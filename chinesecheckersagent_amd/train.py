@@ -242,6 +242,9 @@ class Trainer(object):
         opt_keep = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.opt.state.items()} if had_state else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if quiet is not None:
+            quiet(False)                               # (the warm-up runs on a side stream on purpose)
         with torch.cuda.stream(side):
             for _ in range(3):
                 self.step(self._gx, self._gpi, self._gz)

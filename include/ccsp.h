@@ -161,7 +161,9 @@ enum {
     CCSP_GREEDY_P1 = 1,          /* player one is a GreedyPlayer (game.py:19-20) */
     CCSP_GREEDY_P2 = 2,          /* player two is a GreedyPlayer (game.py:26-27) */
     CCSP_GREEDY_ALTERNATE = 4,   /* seats swap on odd game ids (ai_vs_greedy.py:47-48) */
-    CCSP_GREEDY_RANDOM_START = 8 /* mode 2: GreedyDataGenerator(random_start=True) (data_generators.py:31-40) */
+    CCSP_GREEDY_RANDOM_START = 8,/* mode 2: GreedyDataGenerator(random_start=True) (data_generators.py:31-40) */
+    CCSP_GREEDY_STOCHASTIC_P1 = 16,   /* mode 1: the GreedyPlayer of seat one is GreedyPlayer(stochastic=True) (player.py:68, 77-97; game.py:111) */
+    CCSP_GREEDY_STOCHASTIC_P2 = 32    /* ... of seat two (the two bits swap with the seats under CCSP_GREEDY_ALTERNATE) */
 };
 
 /* one row of the sample log = one entry of selfplay()'s play_history (selfplay.py:128) */

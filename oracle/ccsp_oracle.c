@@ -847,6 +847,41 @@ static int greedy_move(board_t *b, int player, uint64_t seed, uint64_t game, uin
     return 1;
 }
 
+/* GreedyPlayer(stochastic=True).decide_move (player.py:77-97): the moves that go forward (dist > 0) are drawn with probability
+ * proportional to their forward distance -- prior = dist / sum(dist) in float64, np.random.choice(len, p=prior) = the spec's
+ * sample_index (player.py:94-96); with no forward move, a uniform draw among the others (= all moves), player.py:92.  One draw
+ * per ply, the key of the deterministic player's. */
+#define EV_GREEDY_STOCHASTIC 101
+static int greedy_move_stochastic(board_t *b, int player, uint64_t seed, uint64_t game, uint32_t ply, int *id, int *dest) {
+    uint8_t moves[MAXMV][2];
+    int n = valid_moves(b, player, moves, NULL);
+    if (n == 0) return 0;
+    int fw[MAXMV], dist[MAXMV], bw[MAXMV], nf = 0, nb = 0;
+    long sum = 0;
+    for (int i = 0; i < n; i++) {
+        int s = human_row(b->pos[player - 1][moves[i][0]]), e = human_row(moves[i][1]);
+        int d = e - s;                                                                 /* player.py:83 */
+        if (player == 1) d = -d;                                                       /* 84-85 */
+        if (d > 0) { fw[nf] = i; dist[nf] = d; nf++; sum += d; }                       /* 86-88 */
+        else bw[nb++] = i;                                                             /* 89-90 */
+    }
+    uint64_t u = orc_rng(seed, game, ply, 0, 0, P_GREEDY);
+    int pick;
+    if (nf == 0) pick = bw[orc_choice(u, (uint32_t)nb)];                               /* 92 */
+    else {
+        double p[MAXMV];
+        for (int i = 0; i < nf; i++) p[i] = (double)dist[i] / (double)sum;             /* 94 */
+        pick = fw[orc_sample_index(u, p, nf)];                                         /* 95-96 */
+    }
+    *id = moves[pick][0]; *dest = moves[pick][1];
+    return 1;
+}
+
+int orc_greedy_stochastic_move(const uint8_t *pos12, int player, uint64_t seed, uint64_t game, uint32_t ply, int *id, int *dest) {
+    board_t b; board_from_pos12(&b, pos12, NULL);
+    return greedy_move_stochastic(&b, player, seed, game, ply, id, dest);
+}
+
 typedef struct { int status; int reward; int n_plies; int n_hist; int stuck; } orc_greedy_out;
 
 /* GreedyDataGenerator.generate_play (data_generators.py:25-80).  `stuck_limit` replaces the wall-clock
@@ -922,9 +957,10 @@ int orc_arena_game(uint64_t seed, uint64_t game, int sims, int evaluator1, int e
         if (total_moves > TOTAL_MOVES_TILL_TAU0) tau_det[player - 1] = 1;                         /* player.py:152-155 */
         board_t next; orc_search_out so;
         const int seat = player == 1 ? evaluator1 : evaluator2;
-        if (seat == EV_GREEDY) {                                                                  /* GreedyPlayer.decide_move */
+        if (seat == EV_GREEDY || seat == EV_GREEDY_STOCHASTIC) {                                  /* GreedyPlayer.decide_move */
             int id, dest;
-            if (!greedy_move(&b, player, seed, game, (uint32_t)total_moves, &id, &dest)) { out->status = ST_ERROR; break; }
+            if (!(seat == EV_GREEDY ? greedy_move(&b, player, seed, game, (uint32_t)total_moves, &id, &dest)
+                                    : greedy_move_stochastic(&b, player, seed, game, (uint32_t)total_moves, &id, &dest))) { out->status = ST_ERROR; break; }
             so.chosen_id = id; so.chosen_dest = dest; so.evals = 0;
         } else if (make_move_ex(&b, player, seed, game, (uint32_t)total_moves, sims, tau_det[player - 1],
                                 seat, NULL, NULL, &next, &so, NULL, 1)) { out->status = ST_ERROR; break; }

@@ -644,6 +644,67 @@ def gen_greedy():
         json.dump(dict(seed=SEED, limit=LIMIT, policy=policy, games=games, arena=arena), f)
 
 
+def gen_greedy_stochastic():
+    """GreedyPlayer(stochastic=True) (player.py:77-97; what game.py:105-113 plays against the deterministic one): single decisions on
+    positions of seeded random play, and whole Game.start games with such seats -> tests/golden/greedy_stochastic.json"""
+    from refenv import ref_game, ref_player, ref_datagen, pos12_of
+    t0 = time.time()
+    to_idx = ref_datagen.board_utils.human_coord_to_np_index
+    decisions = []
+    for g in range(240):
+        root = board_after_random_plies(12000 + g, 2 + (g * 5) % 44, randomised=(g % 4 == 3))
+        b = root.state
+        if b.check_win():
+            continue
+        for pl in (1, 2):
+            ctx.seed, ctx.game, ctx.ply = SEED, 12000 + g, 3 * g + pl
+            with quiet():
+                frm, to = ref_player.GreedyPlayer(player_num=pl, stochastic=True).decide_move(b)
+            decisions.append(dict(pos12=pos12_of(b), player=pl, game=12000 + g, ply=3 * g + pl,
+                                  move=[b.checkers_id[pl][tuple(frm)], int(to[0]) * 7 + int(to[1])]))
+    arena = []
+    orig_ai = ref_player.AiPlayer.decide_move
+    orig_gr = ref_player.GreedyPlayer.decide_move
+    plan = [(12500, 's', 'g', 0, 0, False), (12501, 'g', 's', 0, 0, False), (12502, 's', 's', 0, 0, False), (12503, 's', 's', 0, 0, True),
+            (12504, 'a', 's', spec.EVAL_FORWARD, 8, False), (12505, 's', 'a', spec.EVAL_HASH, 16, True), (12506, 's', 'g', 0, 0, True),
+            (12507, 'g', 's', 0, 0, True)]
+    for game, p1, p2, ev, sims, enforce in plan:
+        refenv.set_sims(max(sims, 1))
+        ctx.seed, ctx.game = SEED, game
+        m = refenv.TableModel(ev)
+        moves = []
+
+        def wrap(orig):
+            def decide(self, board, verbose=False, training=False, total_moves=None):
+                ctx.ply = total_moves
+                frm, to = orig(self, board, verbose=verbose, total_moves=total_moves)
+                moves.append([board.checkers_id[self.player_num][tuple(frm)], int(to[0]) * 7 + int(to[1])])
+                return frm, to
+            return decide
+        ref_player.AiPlayer.decide_move = wrap(orig_ai)
+        ref_player.GreedyPlayer.decide_move = wrap(orig_gr)
+        try:
+            with quiet():
+                kind = {'a': 'a', 'g': 'g', 's': 'g'}
+                gm = ref_game.Game(p1_type=kind[p1], p2_type=kind[p2], verbose=False, model1=m, model2=m)
+                if p1 == 's':
+                    gm.player_one = ref_player.GreedyPlayer(player_num=1, stochastic=True)       # as game.py:111 does for player two
+                if p2 == 's':
+                    gm.player_two = ref_player.GreedyPlayer(player_num=2, stochastic=True)
+                gm.cur_player, gm.next_player = gm.player_one, gm.player_two                      # (bound at construction, game.py:31-32)
+                winner = gm.start(enforce_move_limit=enforce)
+        finally:
+            ref_player.AiPlayer.decide_move = orig_ai
+            ref_player.GreedyPlayer.decide_move = orig_gr
+        arena.append(dict(game=game, p1=p1, p2=p2, ev=ev, sims=sims, enforce=enforce, winner=winner, moves=moves, evals=m.calls))
+        print('stochastic greedy arena: %d %s/%s winner=%s moves=%d %.0fs' % (game, p1, p2, winner, len(moves), time.time() - t0), file=sys.stderr)
+    with open(os.path.join(OUT, 'greedy_stochastic.json'), 'w') as f:
+        json.dump(dict(seed=SEED, decisions=decisions, arena=arena), f)
+
+
+if __name__ == '__main__' and 'greedy_stochastic' in sys.argv[1:]:
+    gen_greedy_stochastic()
+
 # (game, randomised, random_start) found with the oracle (tests/oracle_ffi.py) whose generator game gets stuck:
 # none in 6000 normal starts, 2 in 3000 randomised boards
 GREEDY_EXTRA = [(20178, True, False), (22641, True, False)]

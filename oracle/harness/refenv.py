@@ -246,6 +246,28 @@ ref_player.random = _GreedyRandom()
 ref_datagen.random = _GreedyRandom()
 
 
+class _PlayerNpRandom(object):
+    """stands in for np.random inside player.py: GreedyPlayer(stochastic=True) draws the index of a forward move with
+    probability proportional to its forward distance (player.py:94-96: np.random.choice(len(forward_moves), p=prior)) -- the ply's
+    ONE greedy draw, read through spec.sample_index (cumulative sums, / last, first one above u) like MCTS.py:140's"""
+
+    @staticmethod
+    def choice(a, size=None, replace=True, p=None):
+        assert p is not None and isinstance(a, int)
+        u = spec.rng(ctx.seed, ctx.game, ctx.ply, 0, 0, spec.P_GREEDY)
+        return spec.sample_index(u, [float(x) for x in p])
+
+
+class _PlayerNpShim(object):
+    random = _PlayerNpRandom()
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+ref_player.np = _PlayerNpShim()
+
+
 class FakeClock(object):
     """data_generators.py:61 declares a game stuck after STUCK_TIME_LIMIT (0.1 s) of WALL CLOCK.  The restatement
     counts plies instead: now() advances 0.1 s / limit per call (one call when the game starts, one after every

@@ -200,6 +200,18 @@ def selfplay(seed, game, sims, evaluator, randomised=False, fn=None, max_plies=1
 
 
 EV_GREEDY = 100          # a GreedyPlayer seat in arena_game (next-4)
+EV_GREEDY_STOCHASTIC = 101   # GreedyPlayer(stochastic=True)
+
+
+def greedy_stochastic_move(pos12, player, seed, game, ply):
+    """GreedyPlayer(stochastic=True).decide_move: (id, dest), or None without a legal move"""
+    L = lib()
+    L.orc_greedy_stochastic_move.restype = C.c_int
+    L.orc_greedy_stochastic_move.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    a = np.ascontiguousarray(pos12, dtype=np.uint8)
+    cid, dest = C.c_int(), C.c_int()
+    ok = L.orc_greedy_stochastic_move(a.ctypes.data_as(C.POINTER(C.c_uint8)), int(player), seed, game, ply, C.byref(cid), C.byref(dest))
+    return (cid.value, dest.value) if ok else None
 
 
 def greedy_best(pos12, player):

@@ -108,6 +108,56 @@ def test_greedy_arena_seats(doc):
         assert (int(res['status'][k]) if int(res['status'][k]) in (1, 2) else 0) == (o['winner'] or 0), k
 
 
+def test_stochastic_greedy_seats(golden_dir):
+    """GreedyPlayer(stochastic=True) seats of Game.start (player.py:77-97, game.py:111) on the GPU: the reference's eight games
+    (against the deterministic greedy player, itself and AiPlayers: tests/golden/greedy_stochastic.json) move for move through
+    the result table, and 96 more games of every seating against the oracle; greedy.greedy_vs_greedy(stochastic=...)"""
+    from chinesecheckersagent_amd import _lib, engine, greedy
+    doc = json.load(open(golden_dir + '/greedy_stochastic.json'))
+    seed = doc['seed']
+    G1, G2, S1, S2 = _lib.GREEDY_P1, _lib.GREEDY_P2, _lib.GREEDY_STOCHASTIC_P1, _lib.GREEDY_STOCHASTIC_P2
+    bits = {('s', 'g'): G1 | G2 | S1, ('g', 's'): G1 | G2 | S2, ('s', 's'): G1 | G2 | S1 | S2, ('a', 's'): G2 | S2, ('s', 'a'): G1 | S1}
+    for g in doc['arena']:
+        e = engine.SelfPlayEngine(n_slots=1, sims=max(g['sims'], 1), seed=seed, first_game=g['game'], max_games=1, log_capacity=1024,
+                                  arena=True, enforce_move_limit=g['enforce'], greedy=bits[(g['p1'], g['p2'])])
+        for _ in range(64):
+            e.play_plies(g['ev'], 16)
+            if e.slots()['status'][0] != 0:
+                break
+        res, final = e.results()[0], e.slots()
+        e.close()
+        tag = 'stochastic greedy arena game %d' % g['game']
+        winner = int(res['status']) if int(res['status']) in (1, 2) else None
+        assert winner == g['winner'] and int(res['n_plies']) == len(g['moves']) and int(res['expansions']) == g['evals'], tag
+        # the final position is the one the reference's move list leads to
+        pos, last, player = orc.initial_pos12(), orc.NO_LAST.copy(), 1
+        for cid, dest in g['moves']:
+            pos, last, _ = orc.step(pos, last, player, cid, dest)
+            player = 3 - player
+        assert [int(x) for x in final['state'][0]['pos'].reshape(12)] == [int(x) for x in pos], tag
+    # every seating against the oracle, 32 games each in one batch
+    code = {'g': orc.EV_GREEDY, 's': orc.EV_GREEDY_STOCHASTIC}
+    for (p1, p2), b in (('s', 'g'), bits[('s', 'g')]), (('g', 's'), bits[('g', 's')]), (('s', 's'), bits[('s', 's')]):
+        n, first = 32, 13000
+        e = engine.SelfPlayEngine(n_slots=n, sims=1, seed=seed, first_game=first, max_games=n, log_capacity=1, arena=True, greedy=b)
+        for _ in range(64):
+            e.play_plies(0, 32)
+            if (e.slots()['status'] != 0).all():
+                break
+        res, final = e.results(), e.slots()
+        e.close()
+        for k in range(n):
+            o = orc.arena_game(seed, first + k, 1, code[p1], code[p2], True, False)
+            assert int(res['n_plies'][k]) == len(o['moves']) and (int(res['status'][k]) if int(res['status'][k]) in (1, 2) else 0) == (o['winner'] or 0), (p1, p2, k)
+            pos, last, player = orc.initial_pos12(), orc.NO_LAST.copy(), 1
+            for cid, dest in o['moves']:
+                pos, last, _ = orc.step(pos, last, player, cid, dest)
+                player = 3 - player
+            assert [int(x) for x in final['state'][k]['pos'].reshape(12)] == [int(x) for x in pos], (p1, p2, k)
+    c = greedy.greedy_vs_greedy(64, seed=seed, first_game=14000, stochastic=(False, True))
+    assert c[1] + c[2] + c[None] == 64 and c[1] + c[2] > 0
+
+
 def test_greedy_api():
     from chinesecheckersagent_amd import greedy, selfplay
     m = TableModel(2)

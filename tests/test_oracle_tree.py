@@ -184,3 +184,19 @@ def test_greedy_policy_games_and_arena(golden_dir):
         tag = 'greedy arena game %d' % g['game']
         assert [[int(a), int(b)] for a, b in o['moves']] == g['moves'], tag
         assert (o['winner'] or None) == g['winner'] and o['evals'] == g['evals'], tag
+
+
+def test_stochastic_greedy_player_against_the_reference(golden_dir):
+    """GreedyPlayer(stochastic=True) (player.py:77-97): 480 single decisions and 8 whole Game.start games with such seats
+    (against the deterministic greedy player, itself, and AiPlayers) made by the reference (tests/golden/greedy_stochastic.json)"""
+    doc = json.load(open(golden_dir + '/greedy_stochastic.json'))
+    seed = doc['seed']
+    for c in doc['decisions']:
+        assert list(orc.greedy_stochastic_move(c['pos12'], c['player'], seed, c['game'], c['ply'])) == c['move'], c
+    code = {'g': orc.EV_GREEDY, 's': orc.EV_GREEDY_STOCHASTIC}
+    assert {(g['p1'], g['p2']) for g in doc['arena']} >= {('s', 'g'), ('g', 's'), ('s', 's'), ('a', 's'), ('s', 'a')}
+    for g in doc['arena']:
+        o = orc.arena_game(seed, g['game'], max(g['sims'], 1), code.get(g['p1'], g['ev']), code.get(g['p2'], g['ev']), True, g['enforce'])
+        tag = 'stochastic greedy arena game %d' % g['game']
+        assert [[int(a), int(b)] for a, b in o['moves']] == g['moves'], tag
+        assert (o['winner'] or None) == g['winner'] and o['evals'] == g['evals'], tag

@@ -30,7 +30,7 @@ for i, n in enumerate(names):
     d = t[i + 1] - t[i]
     key = n.split('.')[-1] if n.startswith('b') else n
     agg[key] = agg.get(key, 0) + d
-print('total ticks (after input load) %d' % tot)
+print('total ticks (after input load) %d; input planes -> LDS before that: %d ticks' % (tot, t[0] - int(out[62])))
 for k, v in agg.items():
     print('  %-16s %7d  %5.1f%%' % (k, v, 100.0 * v / tot))
 
