@@ -507,6 +507,14 @@ def main():
                          'in_pipeline_ms_per_launch': info['t_play'] / launches * 1e3,
                          'in_pipeline_frac': info['n_pos'] * NET_FLOP_PER_EVAL / (info['t_play'] / launches) / 1e12 / MFMA_F32_PEAK_TFLOPS},
         }
+        try:                                 # HBM bytes of one launch by the counters (static: a --pmc pass cannot run inside this process)
+            prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))['net_forward_kernel']
+            if info['n_pos'] == prof['n']:
+                out['roofline']['traffic'] = (2.0 * prof['fetch_size_kb'] + prof['write_size_kb']) * 1024.0
+                out['roofline']['traffic_source'] = 'static: ' + prof['source']
+                out['roofline']['algorithmic_bytes_per_launch'] = info['n_pos'] * (343 * 4 + 294 * 8 + 4) + 4 * 250880   # planes in, p and v out, the weights once
+        except (OSError, KeyError, ValueError) as ex:
+            out['roofline']['traffic_source'] = 'profiles/counters.json not usable: %r' % (ex,)
         if tot3['errors']:
             raise SystemExit('config 3 counted %d engine errors' % tot3['errors'])
 

@@ -273,3 +273,20 @@ def test_game_store_streams_the_rows_log_to_train_data_gives_at_once():
                 assert r == int(full['reward'][j]) and len(h) == length[j]
             else:
                 assert (h, r) == (None, None)
+
+
+def test_parallel_generator_fails_loudly_without_a_gpu(tmp_path):
+    """selfplay.generate_self_play_in_parallel / train.evolve_in_parallel start their rank processes from a parent that makes no GPU
+    call; in this container the ranks have no GPU and must stop at require_gpu() -- no CPU fallback -- and the parent must turn that
+    into an exception (the surviving rank is terminated, nothing is returned)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: covered by the -m gpu tests')
+    from chinesecheckersagent_amd import _lib, selfplay as sp, train as tr
+    w = os.path.join(ROOT, 'tests', 'golden', 'good_model.h5')
+    with pytest.raises(_lib.CcspError, match='rank process failed'):
+        sp.generate_self_play_in_parallel(w, 4, 2, sims=4, seed=1, first_game=0, out_dir=str(tmp_path))
+    assert not [f for f in os.listdir(str(tmp_path)) if f.startswith('selfplay-rank')]
+    with pytest.raises(RuntimeError, match='rank process failed'):
+        tr.evolve_in_parallel(2, w, iterations=1, num_self_play=2, eval_games=2, sims=4, seed=1, work_dir=str(tmp_path),
+                              data_dir=str(tmp_path / 'd'), weights_dir=str(tmp_path / 'w'))
