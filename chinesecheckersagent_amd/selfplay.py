@@ -423,8 +423,8 @@ class SelfPlayRun(object):
     a function of its id alone), two half-batches on their own streams when the batch is large, the sample log harvested
     every `harvest_every` plies -- so device memory is n_slots tree pools + n_slots x (harvest_every + 1) log rows whatever
     n_games is, and the log cannot overflow.
-    `sink(board_x, pi_y, v_y)` (optional) receives the training rows of the games that ended, harvest by harvest, from a
-    worker thread that converts while the GPU plays on."""
+    `sink(board_x, pi_y, v_y, game_ids)` (optional; e.g. a TrainDataSink) receives the training rows of the games that ended,
+    harvest by harvest, from a worker thread that converts while the GPU plays on."""
 
     def __init__(self, model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False, first_game=0,
                  game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY, use_graph=True, keep_records=True,
