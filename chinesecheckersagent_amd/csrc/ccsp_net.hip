@@ -85,36 +85,49 @@ constexpr int PAD0 = 7, PADPOS = 36;
 // A workgroup of NW waves carries NB positions (rows = position * 25 + cell, MT tiles of 16 rows).  Two shapes are built:
 //   <8, 8>: 200 rows = 13 tiles (4 % padding), one 137-KB workgroup per CU, two waves per SIMD from the SAME workgroup --
 //           at every barrier both are out of matrix work at once;
-//   <4, 4>: 100 rows = 7 tiles (12 % padding), 72 KB: TWO workgroups per CU, a SIMD's two waves belong to different
-//           workgroups whose barriers fall at different times, so one's epilogue / barrier / prologue sits under the other's MFMAs.
-// Tile shares (both shapes): 64-column layers -- wave & 3 = column tile, 7 row tiles from 6 * (wave >> 2) (with 8 waves the two
-// halves both compute tile 6); 32-column layers -- wave & 1 = column tile, three row tiles from 3 * (wave >> 1) plus a 1/NSPLIT
-// share of the k-range of the last tile MT - 1.
+//   <4, 4>: 100 rows = 7 tiles (12 % padding), 72 KB, four waves: a workgroup is done in 0.6 of the time -- the shape of batches that
+//           do not fill the GPU (up to 1024 positions), whose launch is as long as one workgroup;
+//   <2, 8>: 50 rows = 4 tiles (22 % padding), 51 KB, eight waves with ONE tile job each in the 32-column layers: the shape of
+//           the smallest batches (one game of selfplay(), the arena's few games per GPU), where only latency counts.
+// Tile shares: 64-column layers -- wave & 3 = column tile, F64 row tiles from M64 * (wave >> 2) (in <8, 8> the two halves both
+// compute tile 6); 32-column layers -- wave & 1 = column tile, F32 row tiles from F32 * (wave >> 1) plus, where the tiles do not
+// divide (XT), a 1/NSPLIT share of the k-range of the last tile MT - 1.  Every shape forms every output by the same chains in the
+// same order: a position's result does not depend on the shape.
 template <int NBv, int NWv>
 struct Cfg {
     static constexpr int NB = NBv, NW = NWv, NTH = NWv * 64, ROWS = NBv * 25, MT = (NBv * 25 + 15) / 16;
-    static constexpr int NSPLIT = NWv / 2;                       // waves sharing the k-range of tile MT - 1 of a 32-column layer
+    static constexpr int NSPLIT = NWv / 2;                       // row groups of the 32-column layers = waves sharing the k-range of tile MT - 1
+    static constexpr int F32 = MT / NSPLIT;                      // full row tiles per wave in the 32-column layers (3, 3, 1)
+    static constexpr int XT = MT - F32 * NSPLIT;                 // 1: a last row tile shared by the NSPLIT waves of a column tile; 0: none
+    static constexpr int NH = NWv / 4;                           // row halves of the 64-column layers
+    static constexpr int F64 = (MT + NH - 1) / NH;               // row tiles per wave in the 64-column layers (7, 7, 2)
+    static constexpr int M64 = MT - F64;                         // first tile of the second half (6: tile 6 twice; 0; 2)
+    static constexpr bool DUP = NH == 2 && 2 * F64 > MT;         // the halves overlap in one tile: stored by the first half only
+    static constexpr bool PADFULL = F32 * NSPLIT * 16 > ROWS;    // the "full" tiles of the 32-column layers hold padding rows
+    static constexpr int HB = NBv < 4 ? 4 : NBv;                 // positions the heads are laid out for (the 4 x 4 MFMA carries four at a time)
     static constexpr int NSEG = 4;                               // k-segments every output of a 3x3 layer is summed from (gemm_tiles_split): the
                                                                  // SAME in every shape, so that both shapes compute a position with the same bits
     static constexpr int PADROWS = PAD0 + NBv * PADPOS + 1;
     static constexpr int INROWS = NBv * 49 + 56;                 // staged input planes + what padding rows / the zero-weight 10th tap reach
     static constexpr int NTW = (19 + NWv - 1) / NWv;             // policy dense: column tiles per wave
-    static_assert(MT - 1 == 3 * NSPLIT && MT <= 13 && (NWv == 4 || NWv == 8), "tile shares assume 3 full row tiles per wave");
+    static_assert((XT == 0 || XT == 1) && F32 >= 1 && F32 <= 3 && F64 <= 7 && MT <= 13 && (NWv == 4 || NWv == 8), "tile shares");
 };
 
 template <typename C>
 struct Smem {
-    float x[C::MT * 16 * LDX];           // 64-channel trunk activations
+    float x[C::MT * 16 * LDX > 4 * C::HB * 320 ? C::MT * 16 * LDX : 4 * C::HB * 320];   // 64-channel trunk activations; the policy dense
+                                         // layer's partial sums [4][HB][320] alias it
     float y1[C::PADROWS * LDY];          // 32-channel 1x1 output = 3x3 input, zero halo; the stem's input planes and the policy
                                          // conv output alias it
     float y2[C::MT * 16 * LDY];          // 32-channel 3x3 output; logits / value scratch alias it
     float part[2][C::NSEG][256];         // partial sums (one per k-segment) of the k-split last row tile of the 3x3 layers
     static_assert(C::INROWS * LDI <= C::PADROWS * LDY, "the staged input planes alias y1");
-    static_assert(C::MT * 16 * 16 <= C::PADROWS * LDY, "the policy conv output aliases y1");
-    static_assert(256 + C::NB * (NPOL_PAD + 32) <= C::MT * 16 * LDY, "logits and value scratch alias y2");
+    static_assert(C::MT * 16 * 16 <= C::PADROWS * LDY && C::HB * 400 <= C::PADROWS * LDY, "the policy conv output aliases y1");
+    static_assert(256 + C::HB * (NPOL_PAD + 32) <= C::MT * 16 * LDY, "logits and value scratch alias y2");
 };
 static_assert(sizeof(Smem<Cfg<8, 8>>) + 3 * 6900 <= 160 * 1024, "<8,8>: one evaluator workgroup per CU plus three tree-kernel workgroups");
 static_assert(2 * sizeof(Smem<Cfg<4, 4>>) + 7800 <= 160 * 1024, "<4,4>: two evaluator workgroups per CU plus a tree-kernel workgroup");
+static_assert(sizeof(Smem<Cfg<2, 8>>) <= 64 * 1024, "<2,8>: a small workgroup");
 
 // the packed weights as a buffer resource: loads take a scalar byte offset (+ the lane's 16 bytes), no vector address math
 struct WBuf {
@@ -250,9 +263,11 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
         for (int c = 1; c < NSEG; c++) sum = sum + acc[i][c];            // the order in which the shared tile's partial sums are added up by its consumer
         epi(mt0 + i, sum, i);
     }
+    if (kpart >= 0) {                                                   // (kpart < 0: a shape without a shared tile)
 #pragma unroll
-    for (int c = 0; c < SPW; c++)
-        *reinterpret_cast<f32x4 *>(&part[(kpart * SPW + c) * 256 + lane * 4]) = accx[c];      // D-fragment order: [segment][lane][reg]
+        for (int c = 0; c < SPW; c++)
+            *reinterpret_cast<f32x4 *>(&part[(kpart * SPW + c) * 256 + lane * 4]) = accx[c];  // D-fragment order: [segment][lane][reg]
+    }
 }
 
 // The same share-out for the SHORT 32-column layers (the blocks' first 1x1, K = 64): there a reduction pass and its two
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                                                              float *__restrict__ logits_out, double *__restrict__ p_out,
                                                              float *__restrict__ v_out) {
     constexpr int NB = C::NB, NTH = C::NTH, ROWS = C::ROWS, MT = C::MT, NSPLIT = C::NSPLIT, PADROWS = C::PADROWS, INROWS = C::INROWS,
-                  NW = C::NW, NTW = C::NTW;
+                  NW = C::NW, F32 = C::F32, F64 = C::F64, M64 = C::M64, XT = C::XT, HB = C::HB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem<C> &S = *reinterpret_cast<Smem<C> *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -361,22 +376,23 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     if (blockIdx.x == 0 && threadIdx.x == 0) net_stamps[60] = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    const int nt2 = wave & 1, qr = wave >> 1, mt3 = 3 * qr;      // this wave's share of the 32-column layers (see below)
+    const int nt2 = wave & 1, qr = wave >> 1, mt3 = F32 * qr;    // this wave's share of the 32-column layers (see below)
+    const int kshare = XT ? qr : -1;                             // its share of the last tile's k-range (none in a shape without one)
     f32x4 pre[NPREMAX];                                          // the next layer's first weight k-blocks, in flight across barriers
     auto bias4 = [&](int off) -> f32x4 { return *reinterpret_cast<const f32x4 *>(W + off + 4 * q); };   // this lane's four output channels
     auto relu4 = [](const f32x4 &v) -> f32x4 { return f32x4{relu(v[0]), relu(v[1]), relu(v[2]), relu(v[3])}; };
 
     // The trunk's tiles have the same owner in the stem and in every block's last layer (column tile wave & 3, row tiles 6 (wave >> 2)
     // .. + 6): the owner keeps its seven tiles in registers as well, so that the residual add needs no LDS read.
-    f32x4 xr[7];
+    f32x4 xr[F64];
     // ---- stem: 3x3 valid, K = 9 taps x 8 -> 5 k-blocks of 2 taps (10th tap = zero weights) -----------
     // A row's nine taps are plain offsets from its top-left input cell (valid convolution); rows past the 200th and the
     // zero-weight 10th tap read staged zeros.  No masks in the loop.
     {
-        const int nt = wave & 3, mt0 = (wave >> 2) * 6;        // 4 column tiles x 2 row halves: tiles 0-6 and 6-12 (tile 6 twice: a plain store)
-        int sbase[7];
+        const int nt = wave & 3, mt0 = (wave >> 2) * M64;      // 4 column tiles x row halves: <8,8> tiles 0-6 and 6-12 (tile 6 twice: a plain store)
+        int sbase[F64];
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
+        for (int i = 0; i < F64; i++) {
             const int row = (mt0 + i) * 16 + l15;
             const int s = row / 25, pos = row % 25;
             sbase[i] = (s * 49 + (pos / 5) * 7 + (pos % 5)) * LDI + (q & 1) * 4;
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
         };
         prefetch<5>(wb, LAY.stem_w, nt, pre);
-        gemm_tiles<7, 5>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
+        gemm_tiles<F64, 5>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
     }
     __syncthreads();
     // the staged planes are dead: y1 becomes the zero-halo 3x3 input (only interior cells are ever written again)
@@ -409,17 +425,20 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     // Per slot (0-2: the full tiles; 3: tile 12), once for all nine blocks:
     //   a3[i]     element offset in y1 of the row's TOP-LEFT tap (zero-halo copy): tap (dr, dc) is + (dr*6 + dc) * LDY
     //   prow[i]   element offset in y1 of the interior cell of this lane's row of tile i (1x1 epilogue -> 3x3 input)
-    int a3[4], prow[3];
+    int a3[F32 + 1], prow[F32];
+    bool prow_ok[F32];                                         // (PADFULL shapes: is this lane's row of the tile a real cell?)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int row = (i < 3 ? mt3 + i : MT - 1) * 16 + l15;
+    for (int i = 0; i < F32 + 1; i++) {
+        int row = (i < F32 ? mt3 + i : MT - 1) * 16 + l15;
         if (row >= ROWS) row -= 25;                            // padding rows of the last tile: any valid cell (results never read)
         const int s = row / 25, pos = row % 25;
         a3[i] = (s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;              // = cell (r - 1, c - 1): PAD0 - 7 = 0
     }
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int row = (mt3 + i) * 16 + l15;                  // < 192: always a real cell
+    for (int i = 0; i < F32; i++) {
+        int row = (mt3 + i) * 16 + l15;                        // <8,8>, <4,4>: always a real cell
+        prow_ok[i] = row < ROWS;
+        if (row >= ROWS) row -= 25;
         const int s = row / 25, pos = row % 25;
         prow[i] = (PAD0 + s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;
     }
@@ -438,13 +457,17 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             };
             const f32x4 bv = bias4(LAY.l1_b[blk] + nt2 * 16);
             auto epi = [&](int, const f32x4 &acc, int i) {
-                *reinterpret_cast<f32x4 *>(&S.y1[(i == 0 ? prow[0] : (i == 1 ? prow[1] : prow[2])) + nt2 * 16]) = relu4(acc + bv);
+                const int at = i == 0 ? prow[0] : (i == 1 ? prow[F32 > 1 ? 1 : 0] : prow[F32 > 2 ? 2 : 0]);
+                if constexpr (C::PADFULL) {
+                    if (!(i == 0 ? prow_ok[0] : (i == 1 ? prow_ok[F32 > 1 ? 1 : 0] : prow_ok[F32 > 2 ? 2 : 0]))) return;
+                }
+                *reinterpret_cast<f32x4 *>(&S.y1[at + nt2 * 16]) = relu4(acc + bv);
             };
             auto epix = [&](const f32x4 &acc) {                                 // the last tile: its real rows only
                 if (l15 < ROWS - (MT - 1) * 16) *reinterpret_cast<f32x4 *>(&S.y1[prowx + nt2 * 16]) = relu4(acc + bv);
             };
-            gemm_tiles_last<3, 4, NSPLIT>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, qr, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); },
-                                          epi, epix);
+            gemm_tiles_last<F32, 4, NSPLIT>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); },
+                                            epi, epix);
         }
         __syncthreads();
         NET_STAMP(2 + 3 * blk);
@@ -457,8 +480,8 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             auto epi = [&](int mt, const f32x4 &acc, int i) {
                 *reinterpret_cast<f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + nt2 * 16 + 4 * q]) = relu4(acc + bv);
             };
-            gemm_tiles_split<3, 18, C::NSEG, NSPLIT>(wb, LAY.l2_w[blk], nt2, mt3, MT - 1, qr, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
-                                                     &S.part[nt2][0][0]);
+            gemm_tiles_split<F32, 18, C::NSEG, NSPLIT>(wb, LAY.l2_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
+                                                       &S.part[nt2][0][0]);
             NET_STAMP(32 + blk);                             // diagnostic: wave 0 done with its share of the 3x3 layer
 #ifdef CCSP_STAMPS
             if (blockIdx.x == 0 && lane == 0 && blk == 4) {
@@ -470,11 +493,11 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         __syncthreads();
         NET_STAMP(3 + 3 * blk);
         {   // 1x1 32 -> 64 + residual: 4 column tiles x 2 row halves
-            const int nt = wave & 3, half = wave >> 2, mt0 = half * 6;       // tiles 0-6 and 6-12: tile 6 is computed by both halves ...
+            const int nt = wave & 3, half = wave >> 2, mt0 = half * M64;     // <8,8>: tiles 0-6 and 6-12: tile 6 is computed by both halves ...
             // The 3x3 layer's k-split tile (MT - 1) is consumed straight from its partial sums -- no reduction pass, no two extra
             // barriers: part[nt2][c][lane * 4 + j] is, for THIS lane's (row, k-slot), exactly what an activation fragment of
             // k-block nt2 holds, so the waves whose share ends with that tile form ((c0 + c1) + c2) + c3 + bias, ReLU in registers.
-            const bool has_x = mt0 + 6 == MT - 1;                           // wave-uniform
+            const bool has_x = XT && mt0 + F64 - 1 == MT - 1;               // wave-uniform
             f32x4 ax[2];
             if (has_x) {
 #pragma unroll
@@ -486,16 +509,16 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 }
             }
             auto afrag = [&](int mt, int kb, int i) -> f32x4 {
-                if (i == 6 && has_x) return ax[kb];
+                if (i == F64 - 1 && has_x) return ax[kb];
                 return *reinterpret_cast<const f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + kb * 16 + 4 * q]);
             };
             const f32x4 bv = bias4(LAY.l3_b[blk] + nt * 16);
             auto epi = [&](int mt, const f32x4 &acc, int i) {
                 xr[i] = relu4(acc + bv + xr[i]);                                // add([x, block_input]) then ReLU; the input from registers
-                if (half && mt == 6) return;                                    // ... and stored by the first half only
+                if (C::DUP && half && i == 0) return;                           // ... and stored by the first half only
                 *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
             };
-            gemm_tiles<7, 2>(wb, LAY.l3_w[blk], nt, mt0, pre, afrag, [&]() {
+            gemm_tiles<F64, 2>(wb, LAY.l3_w[blk], nt, mt0, pre, afrag, [&]() {
                 if (blk < 8) prefetch<4>(wb, LAY.l1_w[blk < 8 ? blk + 1 : 8], nt2, pre);
                 else prefetch<4>(wb, LAY.pc_w, 0, pre);
             }, epi);
@@ -541,10 +564,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     // tiles; both waves of a SIMD together 5), every weight crosses L2 -> registers exactly once per workgroup (16 bytes per lane and
     // group, scalar-addressed, two groups ahead).  The four k-quarters' partial sums meet in LDS (the trunk buffer is dead by now) and
     // every logit is ((q0 + q1) + q2) + q3 + bias -- the same chains for every position, whatever its slot or the workgroup shape.
-    float *part = S.x;                                   // [4][NB][320] partial sums
-    static_assert(4 * NB * 320 <= MT * 16 * LDX, "the dense layer's partial sums alias the trunk buffer");
+    float *part = S.x;                                   // [4][HB][320] partial sums
     {
-        constexpr int GPQ = 25, NHALF = NW / 4, TPW = (5 + NHALF - 1) / NHALF, PG = NB / 4, PDG = CCSP_NET_PDG;
+        constexpr int GPQ = 25, NHALF = NW / 4, TPW = (5 + NHALF - 1) / NHALF, PG = HB / 4, PDG = CCSP_NET_PDG;
         const int kq = wave & 3, th = wave >> 2;
         int woff[TPW];
         bool valid[TPW];
@@ -595,15 +617,15 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
 #pragma unroll
                 for (int g = 0; g < PG; g++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) part[(kq * NB + 4 * g + r) * 320 + T * 64 + lane] = acc[t][g][r];
+                    for (int r = 0; r < 4; r++) part[(kq * HB + 4 * g + r) * 320 + T * 64 + lane] = acc[t][g][r];
             }
         }
     }
     __syncthreads();
     for (int i = tid; i < NB * NPOL; i += NTH) {
         const int s = i / NPOL, col = i - s * NPOL;
-        const float q0 = part[(0 * NB + s) * 320 + col], q1 = part[(1 * NB + s) * 320 + col], q2 = part[(2 * NB + s) * 320 + col],
-                    q3 = part[(3 * NB + s) * 320 + col];
+        const float q0 = part[(0 * HB + s) * 320 + col], q1 = part[(1 * HB + s) * 320 + col], q2 = part[(2 * HB + s) * 320 + col],
+                    q3 = part[(3 * HB + s) * 320 + col];
         lg[s * NPOL_PAD + col] = ((q0 + q1) + q2) + q3 + W[LAY.pf_b + col];
     }
     // ---- value head, part 2: dense 25 -> 32 ReLU (thread = (position, unit)), then 32 -> 1 tanh ---------
@@ -686,6 +708,7 @@ static int launch_net(const float *packed, const float *planes, int n, float *lo
 static int g_net_shape = 0;                   // positions per workgroup: 8 (one workgroup per CU), 4 (two per CU), 0 = by batch size
 #ifndef CCSP_NET_SMALL
 #define CCSP_NET_SMALL 1024                   // batches up to this many positions run in the <4, 4> shape (see ccsp_net_forward)
+#define CCSP_NET_TINY 512                     // ... and up to this many in the <2, 8> shape
 #endif
 
 extern "C" {
@@ -744,19 +767,21 @@ int ccsp_net_pack(const float *plain, float *packed) {
 // Test / measurement hook: pick the workgroup shape of ccsp_net_forward (8 or 4 positions per workgroup; anything else
 // restores the default).  Both shapes compute every position with the same arithmetic in the same order: results are identical.
 int ccsp_debug_net_shape(int positions_per_workgroup) {
-    g_net_shape = (positions_per_workgroup == 4 || positions_per_workgroup == 8) ? positions_per_workgroup : 0;
+    g_net_shape = (positions_per_workgroup == 2 || positions_per_workgroup == 4 || positions_per_workgroup == 8) ? positions_per_workgroup : 0;
     return g_net_shape;
 }
 
 int ccsp_net_forward(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream) {
     if (n < 0 || (n > 0 && (!packed || !planes || !v))) return CCSP_EINVAL;
     if (n == 0) return CCSP_OK;
-    static bool attr8[64] = {false}, attr4[64] = {false};
-    // Both shapes compute a position with the same arithmetic in the same order (bit-identical results), so the choice is one of speed
-    // only: a workgroup of <4, 4> carries 4 positions on 4 waves in about half the time a workgroup of <8, 8> carries 8 on 8, which is what
-    // counts while the batch does not fill the 256 CUs anyway (the arena's 24 games, one game of selfplay(), config 5's small cohorts):
-    // the launch is as long as ONE workgroup.  Large batches want <8, 8>: the policy dense layer's weights cross L2 once per 8 positions.
-    const int shape = g_net_shape ? g_net_shape : (n <= CCSP_NET_SMALL ? 4 : 8);
+    static bool attr8[64] = {false}, attr4[64] = {false}, attr2[64] = {false};
+    // All shapes compute a position with the same arithmetic in the same order (bit-identical results), so the choice is one of speed
+    // only.  While a batch does not fill the 256 CUs its launch is as long as ONE workgroup (tools/bench_net_sizes.py): 116-119 us in
+    // <8, 8> for 1 .. 2048 positions, 75-77 us in <4, 4> up to 1024 (4 positions on 4 waves), 46-48 us in <2, 8> up to 512 (2 positions on 8
+    // waves: one tile job per wave in the 32-column layers) -- the arena's 24 games, one game of selfplay(), config 5's small cohorts.
+    // Large batches want <8, 8>: the policy dense layer's weights cross L2 once per 8 positions.
+    const int shape = g_net_shape ? g_net_shape : (n <= CCSP_NET_TINY ? 2 : (n <= CCSP_NET_SMALL ? 4 : 8));
+    if (shape == 2) return launch_net<Cfg<2, 8>>(packed, planes, n, logits, p, v, stream, attr2);
     if (shape == 4) return launch_net<Cfg<4, 4>>(packed, planes, n, logits, p, v, stream, attr4);
     return launch_net<Cfg<8, 8>>(packed, planes, n, logits, p, v, stream, attr8);
 }

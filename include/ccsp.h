@@ -255,9 +255,9 @@ int ccsp_net_pack(const float *plain, float *packed);
  * packed = device copy of ccsp_net_pack's output. */
 int ccsp_net_forward(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream);
 
-/* test / measurement hook: workgroup shape of ccsp_net_forward -- 8 positions per workgroup (one workgroup per CU) or 4 (two per
- * CU); any other value restores the default: by batch size (small batches, which cannot fill the GPU, run in the shape whose single
- * workgroup is done sooner).  Bit-identical results in both shapes.  Returns the value in force (0 = by batch size). */
+/* test / measurement hook: workgroup shape of ccsp_net_forward -- 8, 4 or 2 positions per workgroup; any other value restores the
+ * default: by batch size (batches that cannot fill the GPU run in the shape whose single workgroup is done sooner: 2 up to 512
+ * positions, 4 up to 1024, 8 beyond).  Bit-identical results in every shape.  Returns the value in force (0 = by batch size). */
 int ccsp_debug_net_shape(int positions_per_workgroup);
 
 /* ---- read-back (synchronous; host buffers unless said otherwise) ----------------------------------- */
