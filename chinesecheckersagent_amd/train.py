@@ -295,10 +295,12 @@ class Trainer(object):
             perm = torch.randperm(split, generator=gen).to(self.device)
             tot, cnt = 0.0, 0
             tot_dev = torch.zeros((), dtype=torch.float64, device=self.device) if graph is not None else None
+            if graph is not None:                       # the epoch's rows in their shuffled order, gathered once: a step is three copies + a replay
+                xe, pe, ze = xt[perm], pt[perm], zt[perm]
             for i in range(0, split, batch_size):
                 idx = perm[i:i + batch_size]
                 if graph is not None and len(idx) == batch_size:
-                    self._gx.copy_(xt[idx]); self._gpi.copy_(pt[idx]); self._gz.copy_(zt[idx])
+                    self._gx.copy_(xe[i:i + batch_size]); self._gpi.copy_(pe[i:i + batch_size]); self._gz.copy_(ze[i:i + batch_size])
                     graph.replay()
                     tot_dev += self._graph_loss.detach().double() * batch_size        # (no host read-back inside the epoch)
                     cnt += batch_size
