@@ -339,6 +339,14 @@ def test_restarting_slots_return_the_records_of_one_slot_per_game(golden_dir, tm
         assert got == want, kw
         assert c['errors'] == 0 and c['games_won'] + c['games_discarded'] == n
     assert _records(sp.selfplay_batch(m, n_games=n, sims=sims, seed=seed, first_game=first, max_slots=6)) == want
+    # randomised starts (Board(randomised=True): the first three rows of a won game are dropped, selfplay.py:76-78) and two models
+    m2 = ResidualCNN()
+    m2.load_weights(golden_dir + '/good_model.h5')
+    b = sp.BatchSelfPlay(m, m2, n_slots=9, sims=sims, seed=seed, first_game=first, max_games=9, randomised=True, log_capacity=9 * 600)
+    want_r = _records(b.run_to_completion(max_plies=1100))
+    b.close()
+    assert _records(sp.selfplay_batch(m, m2, n_games=9, sims=sims, seed=seed, first_game=first, randomised=True, max_slots=4, harvest_every=5)) == want_r
+    assert any(isinstance(h, list) for h, _ in want_r)
     bx, py, vy, summary = sp.generate_train_data(m, n_games=n, sims=sims, seed=seed, first_game=first, max_slots=6, harvest_every=5)
     kept = sp.selfplay_batch(m, n_games=n, sims=sims, seed=seed, first_game=first)
     kept = [(h, r) for h, r in kept if h is not None]
