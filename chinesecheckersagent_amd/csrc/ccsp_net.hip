@@ -117,11 +117,10 @@ template <typename C>
 struct Smem {
     float x[C::MT * 16 * LDX > 4 * C::HB * 320 ? C::MT * 16 * LDX : 4 * C::HB * 320];   // 64-channel trunk activations; the policy dense
                                          // layer's partial sums [4][HB][320] alias it
-    float y1[C::PADROWS * LDY];          // 32-channel 1x1 output = 3x3 input, zero halo; the stem's input planes and the policy
-                                         // conv output alias it
-    float y2[C::MT * 16 * LDY];          // 32-channel 3x3 output; logits / value scratch alias it
+    float y1[C::PADROWS * LDY];          // 32-channel 1x1 output = 3x3 input, zero halo; the policy conv output aliases it
+    float y2[C::MT * 16 * LDY];          // 32-channel 3x3 output; the stem's input planes and the logits / value scratch alias it
     float part[2][C::NSEG][256];         // partial sums (one per k-segment) of the k-split last row tile of the 3x3 layers
-    static_assert(C::INROWS * LDI <= C::PADROWS * LDY, "the staged input planes alias y1");
+    static_assert(C::INROWS * LDI <= C::MT * 16 * LDY, "the staged input planes alias y2");
     static_assert(C::MT * 16 * 16 <= C::PADROWS * LDY && C::HB * 400 <= C::PADROWS * LDY, "the policy conv output aliases y1");
     static_assert(256 + C::HB * (NPOL_PAD + 32) <= C::MT * 16 * LDY, "logits and value scratch alias y2");
 };
@@ -364,11 +363,46 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
 #ifdef CCSP_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) net_stamps[62] = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- input planes -> LDS [INROWS][LDI] (channels 7.. and the cells past the 8 positions = 0), aliasing y1 ----------
-    float *in = S.y1;
-    for (int i = tid; i < INROWS * LDI; i += NTH) {
-        const int cellg = i / LDI, ch = i % LDI, s = cellg / 49, cell = cellg % 49;
-        in[i] = (ch < 7 && s < here) ? planes[(s0 + s) * 343 + cell * 7 + ch] : 0.0f;
+    // ---- input planes -> LDS [INROWS][LDI] (channels 7.. and the cells past the 8 positions = 0), aliasing y2 ----------
+    // The workgroup's positions are ONE contiguous run of here * 343 floats (16-byte aligned: NB * 343 * 4 is a multiple of 16 for
+    // even NB): coalesced 16-byte loads, issued before the staging area is zeroed, then every element goes to its (cell, channel) slot
+    // of the 12-float rows.  (Was: one 4-byte load and a handful of divisions per LDS element, pad channels included.)
+    float *in = S.y2;                                          // (dead again before the first 3x3 layer writes y2)
+    // y1, the zero-halo input of the 3x3 layers (only interior cells are ever written again), is cleared in the same phase
+    static_assert((PADROWS * LDY) % 4 == 0, "y1 is cleared 16 bytes at a time");
+    for (int i = tid * 4; i < PADROWS * LDY; i += NTH * 4) *reinterpret_cast<f32x4 *>(&S.y1[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr ((NB * 343) % 4 != 0) {                       // (<2, 8>: 686 floats per workgroup, not a multiple of four: the plain way)
+        for (int i = tid; i < INROWS * LDI; i += NTH) {
+            const int cellg = i / LDI, ch = i % LDI, s = cellg / 49, cell = cellg % 49;
+            in[i] = (ch < 7 && s < here) ? planes[(s0 + s) * 343 + cell * 7 + ch] : 0.0f;
+        }
+    } else {
+        constexpr int NV = (NB * 343) / 4, PER = (NV + NTH - 1) / NTH;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(planes + s0 * 343);
+        const int nreal = here * 343;
+        f32x4 v[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int e = (tid + r * NTH) * 4;
+            v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e + 3 < nreal) v[r] = src[tid + r * NTH];
+            else if (e < nreal) { for (int j = 0; j < 4; j++) if (e + j < nreal) v[r][j] = planes[s0 * 343 + e + j]; }
+        }
+        static_assert((INROWS * LDI) % 4 == 0, "the staging area is cleared 16 bytes at a time");
+        for (int i = tid * 4; i < INROWS * LDI; i += NTH * 4) *reinterpret_cast<f32x4 *>(&in[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int e = (tid + r * NTH) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned ee = (unsigned)(e + j);
+                if ((int)ee < nreal) {
+                    const unsigned cellg = __umulhi(ee, 613566757u);       // ee / 7 (exact for ee < 2^31: 2^32 / 7 rounded up)
+                    in[cellg * LDI + (ee - 7u * cellg)] = v[r][j];
+                }
+            }
+        }
     }
     __syncthreads();
     NET_STAMP(0);
@@ -414,10 +448,6 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         prefetch<5>(wb, LAY.stem_w, nt, pre);
         gemm_tiles<F64, 5>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
     }
-    __syncthreads();
-    // the staged planes are dead: y1 becomes the zero-halo 3x3 input (only interior cells are ever written again)
-    static_assert((PADROWS * LDY) % 4 == 0, "y1 is cleared 16 bytes at a time");
-    for (int i = tid * 4; i < PADROWS * LDY; i += NTH * 4) *reinterpret_cast<f32x4 *>(&S.y1[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     NET_STAMP(1);
 
