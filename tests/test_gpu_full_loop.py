@@ -108,30 +108,36 @@ def test_gpu_training_step_equals_cpu(golden_dir):
 
 def test_fit_on_captured_step_graph_equals_eager_fit(golden_dir):
     """next-2 on one GPU: fit() replays ONE captured hipGraph of the optimisation step per full batch (the step is launch-bound in
-    eager mode); the throw-away steps that warm the capture up leave no trace.  Same data, same seed: the graph fit and the eager
-    fit end with the same weights and moving statistics to float32 noise, and report the same losses."""
-    import torch
+    eager mode); the throw-away steps that warm the capture up leave no trace.  (1) ONE epoch of ONE full batch from the reference's
+    weights: the replayed step and the eager step give the same weights and moving statistics to float32 rounding; (2) two epochs with
+    a ragged last batch: the same losses, weights within the run-to-run spread of float32 training (atomics in the convolutions'
+    backward passes, amplified by BatchNorm on batches of 8: two eager fits differ by ~1e-5, two graph fits by ~1e-4)."""
     from chinesecheckersagent_amd import train as T
     rng = np.random.RandomState(11)
     n = 8 * 13 + 5                                          # 13 full batches of 8 and a ragged one per epoch
     xs = rng.randint(0, 7, size=(n, 7, 7, 7)).astype(np.float32)
     ps = rng.dirichlet(np.ones(294), size=n).astype(np.float32)
     zs = rng.choice([-1, 1], size=n).astype(np.int64)
-    out = []
-    for use_graph in (False, True):
+
+    def fit(use_graph, rows, epochs, split):
         t = T.Trainer()
         t.load_weights(golden_dir + '/good_model.h5')
-        hist = t.fit(xs, ps, zs, batch_size=8, epochs=2, validation_split=0.05, seed=4, use_graph=use_graph)
+        hist = t.fit(xs[:rows], ps[:rows], zs[:rows], batch_size=8, epochs=epochs, validation_split=split, seed=4, use_graph=use_graph)
         assert (getattr(t, '_graph', None) is not None) == use_graph
-        out.append((t.state_as_keras(), hist))
-    (a, ha), (b, hb) = out
-    for k in a:                 # (two eager fits of the same data differ by 6e-6 run to run, two graph fits by 2e-5: float32 atomics)
-        assert np.abs(a[k] - b[k]).max() <= 1e-4 * max(1.0, float(np.abs(a[k]).max())), k
+        return t.state_as_keras(), hist
+    (a, ha), (b, hb) = fit(False, 8, 1, 0.0), fit(True, 8, 1, 0.0)            # (1) one step
+    for k in a:
+        assert np.abs(a[k] - b[k]).max() <= 2e-6 * max(1.0, float(np.abs(a[k]).max())), k
+    assert abs(ha[0][0] - hb[0][0]) < 1e-5 * abs(ha[0][0])
+    w0 = T.Trainer()
+    w0.load_weights(golden_dir + '/good_model.h5')
+    w0 = w0.state_as_keras()
+    assert all(np.abs(a[k] - w0[k]).max() > 0 for k in a if 'moving_mean' in k or 'kernel' in k)      # the step did move everything
+    (a, ha), (b, hb) = fit(False, n, 2, 0.05), fit(True, n, 2, 0.05)         # (2) two epochs
+    for k in a:
+        assert np.abs(a[k] - b[k]).max() <= 1e-3 * max(1.0, float(np.abs(a[k]).max())), k
     for (la, va), (lb, vb) in zip(ha, hb):
-        assert abs(la - lb) < 1e-4 * abs(la) and abs(va - vb) < 1e-4 * abs(va)
-    moved = [k for k in a if 'moving_mean' in k]
-    w0 = T.Trainer(); w0.load_weights(golden_dir + '/good_model.h5')
-    assert any(np.abs(a[k] - w0.state_as_keras()[k]).max() > 0 for k in moved)
+        assert abs(la - lb) < 1e-4 * abs(la) and abs(va - vb) < 1e-3 * abs(va)
 
 
 def test_ddp_training_step_through_rccl_world1(golden_dir, tmp_path):
