@@ -386,7 +386,7 @@ def main():
     ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
     ap.add_argument('--sims', type=int, default=400)
     ap.add_argument('--spread-plies', type=int, default=72, help='untimed plies before the warm-up: the first cohort of games spreads out')
-    ap.add_argument('--harvest-every', type=int, default=8)
+    ap.add_argument('--harvest-every', type=int, default=4)
     ap.add_argument('--min-seconds', type=float, default=1.0, help='shortest timed region: K more steps are added until it is reached')
     ap.add_argument('--fused-plies', type=int, default=192, help='variant 2a: timed plies of the fused kernel')
     ap.add_argument('--no-extras', action='store_true', help='headline region only: no variants, config 5, cpu baseline')

@@ -402,7 +402,7 @@ def test_config1_one_whole_game_50_sims_matches_oracle(golden_dir):
 
 def test_full_size_restarting_run_plays_the_oracles_games(golden_dir):
     """BASELINE config 3 at FULL size in the delivered mode: 4096 restarting slots x 400 simulations with good_model.h5 through
-    SelfPlayRun exactly as bench.py runs it (two half-batches, hipGraphs, harvests every 8 plies, worker thread), until the first
+    SelfPlayRun exactly as bench.py runs it (two half-batches, hipGraphs, harvests every 4 plies, worker thread), until the first
     games have ended; the TWO shortest won games are then replayed by the CPU oracle with a callback into the same evaluator, one
     position per call: every searched position, every pi and z must agree bit for bit.  (What a whole game needs to come out right
     at this size: 400-simulation searches on float32-net priors, the evaluator's independence of its batch slot, the end-of-ply
@@ -413,11 +413,11 @@ def test_full_size_restarting_run_plays_the_oracles_games(golden_dir):
     m = ResidualCNN()
     m.load_weights(golden_dir + '/good_model.h5')
     seed, sims, G = 20261003, 400, 4096
-    run = sp.SelfPlayRun(m, n_games=G * 4, sims=sims, seed=seed, max_slots=G, harvest_every=8)
+    run = sp.SelfPlayRun(m, n_games=G * 4, sims=sims, seed=seed, max_slots=G)
     try:
         won = []
         for _ in range(12):                                   # <= 96 plies: the first games end after ~35 searched plies
-            for _ in range(8):
+            for _ in range(8):                                # (play_ply harvests every sp.HARVEST_EVERY plies by itself)
                 run.play_ply()
             st = run.store.results['status']
             won = np.nonzero((st == _lib.ST_WON_P1) | (st == _lib.ST_WON_P2))[0]
