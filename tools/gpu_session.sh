@@ -37,6 +37,13 @@ for r in csv.DictReader(open(sys.argv[1])):
 # launches of the trace are bench.py's back-to-back burst (the figure `roofline.avg_launch_ms` reports)
 net.sort()
 big = [d for _, d, g in net if g == max(g_ for _, _, g_ in net)]
+full = [(st, d) for st, d, g in net if g == max(g_ for _, _, g_ in net)]
+if len(full) > 900:
+    pp = full[:-500]                                   # the launches inside the timed pipelines, in start order
+    gaps = [pp[i + 1][0] - (pp[i][0] + pp[i][1]) for i in range(len(pp) - 1)]
+    gaps = [x for x in gaps if -200000 < x < 200000]   # (neighbours of the same run of plies)
+    print('net_forward_kernel,in_pipeline_gap_between_consecutive_launches_avg_us,%.3f' % (sum(gaps) / len(gaps) / 1e3))
+    print('net_forward_kernel,in_pipeline_gap_median_us,%.3f' % (sorted(gaps)[len(gaps) // 2] / 1e3))
 if len(big) > 900:
     burst, pipe = big[-400:], big[:-500]
     print('net_forward_kernel,back_to_back_burst_last_400_avg_ms,%.6f' % (sum(burst) / len(burst) / 1e6))
