@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libccsp.so')
+LIB_PATH = os.environ.get('CCSP_LIB') or os.path.join(HERE, 'libccsp.so')        # (CCSP_LIB: an experimental build, tools/ only)
 
 NUM_ACTIONS = 294
 MAX_MOVES = 126

@@ -518,7 +518,7 @@ __device__ __forceinline__ Pick pick_edge(const double *__restrict__ sqrt_tab, c
     return pk;
 }
 
-template <bool RCP>
+template <bool RCP, bool REGPATH = RCP>          // RCP: divisions through a table of reciprocals; REGPATH: the caller keeps the path's first 64 levels in registers
 __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab, const double *rcp, const SimCtx &sl, uint8_t *pool, uint64_t *path, uint32_t sim,
                                             uint64_t &mypath, double &myW, uint32_t &myN, uint32_t &select_edges) {
     const int lane = lane_id();
@@ -554,7 +554,7 @@ __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab,
         }
         const uint64_t entry = path_entry(off >> 3, K, sel);
         if (level < 64) { if (lane == level) { mypath = entry; myW = ccsp_from_bits(w_sel); myN = n_sel; } }   // backup needs no reload
-        if ((!RCP || level >= 64) && lane == 0) path[level] = entry;       // the fused kernel keeps 64 levels in registers
+        if ((!REGPATH || level >= 64) && lane == 0) path[level] = entry;   // the fused kernel keeps 64 levels in registers
         level++;
         if (c_sel != CHILD_LEAF && c_sel != CHILD_TERMINAL) {       // descend (MCTS.py:74)
             off = (c_sel >> 7) << 3;
@@ -1318,6 +1318,8 @@ __device__ __forceinline__ void select_core(const Params &P, Lds &lds, int g, fl
     uint64_t mypath = 0; double myW = 0.0; uint32_t myN = 0;
     SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = (uint32_t)P.arena;
     uint32_t select_edges = 0;
+    // (IEEE divisions here: the fused kernel's table of reciprocals costs a 3.4-KB LDS fill per launch in this short kernel, and read
+    // straight from global memory -- wave_select<true, false>(P.sqrt_tab, P.rcp_tab, ...), round 3 -- it changes nothing measurable)
     const Leaf lf = wave_select<false>(P.sqrt_tab, nullptr, cx, pool, path, sl.sim, mypath, myW, myN, select_edges);
     if (lane_id() == 0) {
         uint32_t *a = P.stepacc + (size_t)g * 8;
