@@ -491,6 +491,7 @@ def main():
                        'games_per_gpu': G, 'sims': S, 'sharding': 'game id mod n_gpus'},
             'games_per_s': done / dt3, 'games_won_per_s': tot3['games_won'] / dt3, 'games_finished': done, 'games_won': tot3['games_won'],
             'samples_per_s': tot3['samples'] / dt3, 'plies_per_s': tot3['plies'] / dt3,
+            'plies_per_game': tot3['plies'] / max(done, 1), 'discard_rate': tot3['games_discarded'] / max(done, 1),
             'train_rows_written': rows_all, 'train_file_bytes': bytes_all,
             'timed_region_s': {'total': dt3, 'plies': info['t_play'], 'final_harvest_and_conversion': info['t_drain'], 'hdf5_close': info['t_write']},
             'ms_per_sim_step': info['t_play'] / steps / (S + 1) * 1e3,
@@ -592,6 +593,12 @@ def main():
                 out['config5'] = {'failed': repr(ex)}
     if rank == 0:
         out['cpu_baseline'] = cpu_baseline(args.cpu_seconds, S, args.cpu_cores) if (extras_wanted and args.cpu_seconds > 0) else None
+        if out['cpu_baseline'] and out['cpu_baseline'].get('kind') == 'port' and out.get('plies_per_game'):
+            # games/s of the CPU legs that play config 3's workload: their node-expansions/s over the evaluator calls of a game as the GPU
+            # run measured it ((sims + 1) per searched ply; plies_per_game counts the six random opening plies too)
+            per_game = (S + 1) * max(out['plies_per_game'] - 6.0, 1.0)
+            out['cpu_baseline']['games_per_s_estimate'] = out['cpu_baseline']['value'] / per_game
+            out['cpu_baseline']['games_per_s_estimate_per_core'] = out['cpu_baseline']['value'] / per_game / out['cpu_baseline']['cores']
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
