@@ -357,9 +357,11 @@ def config5(args, torch, rank, world, local, dist):
         dist.broadcast_object_list(box, src=0)
         work = box[0]
     timings = []
+    if os.environ.get('CCSP_BENCH_TEST_STALL_RANK') == str(rank):    # test hook: this rank never joins the loop's collectives
+        time.sleep(3600)
     try:
         t0 = time.time()
-        cur, best, it = train.evolve(w, best_model=w, iterations=1, num_self_play=args.config5_games * world, eval_games=24,
+        cur, best, it = train.evolve(w, best_model=w, iterations=1, num_self_play=args.config5_games, eval_games=24,
                                      sims=args.config5_sims, seed=SEED, data_dir=os.path.join(work, 'data'),
                                      weights_dir=os.path.join(work, 'weights'), log=lambda *a: None, dist=dist, device=local,
                                      timings=timings)
@@ -371,9 +373,9 @@ def config5(args, torch, rank, world, local, dist):
             shutil.rmtree(work, ignore_errors=True)
     tm = timings[0]
     tm.pop('iteration', None)
-    return dict(workload='config 5 in miniature: train.evolve, one iteration: %d self-play games (%d per GPU) at %d sims/move with %s, '
-                         'augment + save + fit (5 epochs of batch 32%s), arena of 24 games at %d sims with the 100-move limit'
-                         % (args.config5_games * world, args.config5_games, args.config5_sims, os.path.basename(w),
+    return dict(workload='config 5 in miniature: train.evolve, one iteration: %d self-play games (sharded over the %d GPU(s) by id) at %d '
+                         'sims/move with %s, augment + save + fit (5 epochs of batch 32%s), arena of 24 games at %d sims with the '
+                         '100-move limit' % (args.config5_games, world, args.config5_sims, os.path.basename(w),
                             ', DistributedDataParallel' if dist is not None else '', args.config5_sims),
                 wall_s=wall, selfplay_expansions_per_s=tm['selfplay_expansions'] / tm['selfplay_s'], **tm)
 
@@ -391,7 +393,8 @@ def main():
     ap.add_argument('--fused-plies', type=int, default=192, help='variant 2a: timed plies of the fused kernel')
     ap.add_argument('--no-extras', action='store_true', help='headline region only: no variants, config 5, cpu baseline')
     ap.add_argument('--no-config5', action='store_true')
-    ap.add_argument('--config5-games', type=int, default=256, help='config 5: self-play games per GPU')
+    ap.add_argument('--config5-games', type=int, default=256, help='config 5: self-play games of the iteration (all GPUs together, as NUM_SELF_PLAY is)')
+    ap.add_argument('--config5-timeout', type=float, default=300.0, help='N > 1: seconds after which a config 5 that has not come back is given up')
     ap.add_argument('--config5-sims', type=int, default=800)
     ap.add_argument('--cpu-seconds', type=float, default=8.0, help='seconds per CPU-baseline leg; 0 = no CPU baseline')
     ap.add_argument('--cpu-cores', type=int, default=0, help='cap on the worker processes of the CPU baseline (0 = every usable core)')
@@ -580,6 +583,22 @@ def main():
 
     # ---- config 5 in miniature: every rank --------------------------------------------------------------------------------
     if extras_wanted and not args.no_config5 and weights_path():
+        watchdog = None
+        if world > 1:
+            # The N-rank loop is full of collectives; a rank that fails alone leaves the others waiting in one, and this round's boxes
+            # had one GPU to rehearse on.  The measurements above must not be lost to that: after --config5-timeout seconds every rank
+            # gives config 5 up by itself -- rank 0 prints the line it has (config5: failed) -- and exits with status 0.
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    out['config5'] = {'failed': 'not back after %.0f s (watchdog)' % args.config5_timeout}
+                    out['cpu_baseline'] = None
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(args.config5_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             c5 = config5(args, torch, rank, world, local, dist)
             if rank == 0:
@@ -588,9 +607,16 @@ def main():
             if world == 1:
                 raise                                                    # one GPU: tested, a failure is a failure
             # N > 1: the N-rank loop has no N-GPU box to be rehearsed on; its failure must not cost the scaling line
+            # (the other ranks are waiting for this one in a collective: there is no way back into step with them -- this rank leaves
+            # the way the watchdog would, rank 0 with its line; the others follow when their watchdogs fire)
             sys.stderr.write('bench.py: config 5 failed on rank %d: %r\n' % (rank, ex))
             if rank == 0:
                 out['config5'] = {'failed': repr(ex)}
+                out['cpu_baseline'] = None
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        if watchdog is not None:
+            watchdog.cancel()
     if rank == 0:
         out['cpu_baseline'] = cpu_baseline(args.cpu_seconds, S, args.cpu_cores) if (extras_wanted and args.cpu_seconds > 0) else None
         if out['cpu_baseline'] and out['cpu_baseline'].get('kind') == 'port' and out.get('plies_per_game'):
