@@ -989,6 +989,7 @@ __device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot 
     for (int i = lane; i < CCSP_NUM_ACTIONS; i += 64) lds.pi[i] = 0.0;
     __syncthreads();
     uint32_t mvs[2] = {0xFFFFu, 0xFFFFu};
+    bool overflow = false;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int j = lane + 64 * h;
@@ -996,10 +997,16 @@ __device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot 
             const uint32_t n = blk_N(b, K)[j];
             mvs[h] = blk_mv(b, K)[j];
             // pow(N, 1/tau) (MCTS.py:132): tau = 1 -> N exactly; tau = 0.01 -> host libm table of N**100
-            lds.pi[mvs[h]] = sl.det_tau ? P.pow_tab[n] : (double)n;
+            const double pw = sl.det_tau ? P.pow_tab[n] : (double)n;
+            overflow = overflow || (pw > 1.7976931348623157e308);
+            lds.pi[mvs[h]] = pw;
             atomicAdd(&P.visit_hist[mvs[h]], (unsigned long long)n);
         }
     }
+    // N**100 leaves float64 from N = 1210 on: Python's pow(int, float) raises OverflowError there (MCTS.py:132) and the
+    // reference's worker dies with it.  Here the game ends with status ERROR (counted; its slot stays out of play) instead of
+    // handing back pi = inf / inf.  Searches of up to 1209 simulations cannot get there.
+    if (__ballot(overflow)) { sl.status = CCSP_ST_ERROR; slot_finish(P, lds, sl, CCSP_ST_ERROR, tl); return; }
     __syncthreads();
     if (lane == 0) lds.gam[CCSP_MAX_MOVES] = pairwise_294(lds.pi);            // np.sum, MCTS.py:137
     __syncthreads();

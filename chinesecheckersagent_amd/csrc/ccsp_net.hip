@@ -44,6 +44,24 @@ constexpr int NPOL = 294, NPOL_PAD = 304;
 #ifndef CCSP_NET_PDG
 #define CCSP_NET_PDG 1                   // policy dense: groups of four k the weight loads run ahead
 #endif
+// k-segments (accumulation chains) every output of a layer kind is summed from, ((c0 + c1) + c2) + ... in fixed order -- the same in
+// every workgroup shape.  A float32 FMA chain over K terms drifts like sqrt(K) roundings; cutting it into segments of 16-48 k costs
+// NSEG - 1 vector adds per output and no MFMA (tools/n1_floor.py prices the orders).
+#ifndef CCSP_NET_SEG_STEM
+#define CCSP_NET_SEG_STEM 2              // stem 3x3, K = 80 (5 k-blocks: 2 + 3)
+#endif
+#ifndef CCSP_NET_SEG_L1
+#define CCSP_NET_SEG_L1 2                // blocks' first 1x1, K = 64 (4 k-blocks: 2 + 2)
+#endif
+#ifndef CCSP_NET_SEG_L2
+#define CCSP_NET_SEG_L2 4                // blocks' 3x3, K = 288 (18 k-blocks); a multiple of the waves sharing the last row tile (4)
+#endif
+#ifndef CCSP_NET_SEG_L3
+#define CCSP_NET_SEG_L3 1                // blocks' last 1x1, K = 32 (2 k-blocks)
+#endif
+#ifndef CCSP_NET_SEG_PC
+#define CCSP_NET_SEG_PC 1                // policy 1x1, K = 64 (4 k-blocks)
+#endif
 
 // ---- packed weight blob layout (floats) ----------------------------------------------------------------
 struct Layout {
@@ -105,7 +123,7 @@ struct Cfg {
     static constexpr bool DUP = NH == 2 && 2 * F64 > MT;         // the halves overlap in one tile: stored by the first half only
     static constexpr bool PADFULL = F32 * NSPLIT * 16 > ROWS;    // the "full" tiles of the 32-column layers hold padding rows
     static constexpr int HB = NBv < 4 ? 4 : NBv;                 // positions the heads are laid out for (the 4 x 4 MFMA carries four at a time)
-    static constexpr int NSEG = 4;                               // k-segments every output of a 3x3 layer is summed from (gemm_tiles_split): the
+    static constexpr int NSEG = CCSP_NET_SEG_L2;                 // k-segments every output of a 3x3 layer is summed from (gemm_tiles_split): the
                                                                  // SAME in every shape, so that both shapes compute a position with the same bits
     static constexpr int PADROWS = PAD0 + NBv * PADPOS + 1;
     static constexpr int INROWS = NBv * 49 + 56;                 // staged input planes + what padding rows / the zero-weight 10th tap reach
@@ -166,13 +184,16 @@ __device__ __forceinline__ void prefetch(const WBuf &wb, int wbase, int nt, f32x
     for (int d = 0; d < Pre<KBN>::N; d++) pre[d] = wb.load(wbase + nt * KBN * 256 + d * 256);
 }
 
-template <int NMT, int KB, typename AFrag, typename Next, typename Epi>
+template <int NMT, int KB, int NSEG, typename AFrag, typename Next, typename Epi>
 __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, int mt0, f32x4 (&pre)[NPREMAX], AFrag afrag, Next next, Epi epi) {
     constexpr int NPRE = Pre<KB>::N;
     constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;                    // weight ring: PB - 1 k-blocks in flight (L2 latency)
-    f32x4 acc[NMT];
+    static_assert(NSEG >= 1 && NSEG <= KB, "a segment is at least one k-block");
+    f32x4 acc[NMT][NSEG];
 #pragma unroll
-    for (int i = 0; i < NMT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NMT; i++)
+#pragma unroll
+        for (int c = 0; c < NSEG; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int w0 = wbase + nt * KB * 256;
     f32x4 bq[PB];
 #pragma unroll
@@ -182,6 +203,9 @@ __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, in
     for (int i = 0; i < NMT; i++) a[0][i] = afrag(mt0 + i, 0, i);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
+        int seg = 0;                                                    // the segment k-block kb belongs to (static after unrolling)
+#pragma unroll
+        for (int c = 1; c < NSEG; c++) seg += kb >= (KB * c) / NSEG ? 1 : 0;
         if (kb + 1 < KB) {
 #pragma unroll
             for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);   // one k-block ahead (LDS latency)
@@ -192,12 +216,17 @@ __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, in
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < NMT; i++)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i], 0, 0, 0);   // D^T: see tile_out
+                acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
         }
     }
     next();
 #pragma unroll
-    for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i], i);
+    for (int i = 0; i < NMT; i++) {
+        f32x4 sum = acc[i][0];
+#pragma unroll
+        for (int c = 1; c < NSEG; c++) sum = sum + acc[i][c];
+        epi(mt0 + i, sum, i);
+    }
 }
 
 // The 32-column layers have 13 x 2 = 26 tile jobs for 8 waves.  Instead of four jobs on every wave (two of the
@@ -273,15 +302,18 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
 // barriers cost more than the imbalance they remove, so the last row tile is not k-split but computed whole by the wave of
 // each column tile whose share comes last (kpart == NSPLIT - 1).  No tile of these layers is split, so every output is one
 // plain accumulation chain over k -- the same arithmetic for every row without the segment sums of gemm_tiles_split.
-template <int NMT, int KB, int NSPLIT, typename AFrag, typename Next, typename Epi, typename EpiX>
+template <int NMT, int KB, int NSPLIT, int NSEG, typename AFrag, typename Next, typename Epi, typename EpiX>
 __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart, f32x4 (&pre)[NPREMAX],
                                                 AFrag afrag, Next next, Epi epi, EpiX epix) {
     constexpr int NPRE = Pre<KB>::N;
     constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;
+    static_assert(NSEG >= 1 && NSEG <= KB, "a segment is at least one k-block");
     const bool mine = kpart == NSPLIT - 1;                              // wave-uniform
-    f32x4 acc[NMT + 1];
+    f32x4 acc[NMT + 1][NSEG];
 #pragma unroll
-    for (int i = 0; i <= NMT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i <= NMT; i++)
+#pragma unroll
+        for (int c = 0; c < NSEG; c++) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int w0 = wbase + nt * KB * 256;
     f32x4 bq[PB];
 #pragma unroll
@@ -292,6 +324,9 @@ __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int n
     a[0][NMT] = afrag(xmt, 0, NMT);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
+        int seg = 0;                                                    // static after unrolling
+#pragma unroll
+        for (int c = 1; c < NSEG; c++) seg += kb >= (KB * c) / NSEG ? 1 : 0;
         if (kb + 1 < KB) {
 #pragma unroll
             for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
@@ -303,18 +338,23 @@ __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int n
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < NMT; i++)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i], 0, 0, 0);   // D^T: see tile_out
+                acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
         }
         if (mine) {                                                     // ONE scalar branch per k-block
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                acc[NMT] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], acc[NMT], 0, 0, 0);
+                acc[NMT][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], acc[NMT][seg], 0, 0, 0);
         }
     }
     next();
 #pragma unroll
-    for (int i = 0; i < NMT; i++) epi(mt0 + i, acc[i], i);
-    if (mine) epix(acc[NMT]);
+    for (int i = 0; i <= NMT; i++) {
+        f32x4 sum = acc[i][0];
+#pragma unroll
+        for (int c = 1; c < NSEG; c++) sum = sum + acc[i][c];
+        if (i < NMT) epi(mt0 + i, sum, i);
+        else if (mine) epix(sum);
+    }
 }
 
 // ReLU as ONE instruction (v_med3_f32 v, 0, +inf): `v > 0 ? v : 0` costs a canonicalising v_max plus the v_max itself
@@ -446,7 +486,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
         };
         prefetch<5>(wb, LAY.stem_w, nt, pre);
-        gemm_tiles<F64, 5>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
+        gemm_tiles<F64, 5, CCSP_NET_SEG_STEM>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
     }
     __syncthreads();
     NET_STAMP(1);
@@ -496,7 +536,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             auto epix = [&](const f32x4 &acc) {                                 // the last tile: its real rows only
                 if (l15 < ROWS - (MT - 1) * 16) *reinterpret_cast<f32x4 *>(&S.y1[prowx + nt2 * 16]) = relu4(acc + bv);
             };
-            gemm_tiles_last<F32, 4, NSPLIT>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); },
+            gemm_tiles_last<F32, 4, NSPLIT, CCSP_NET_SEG_L1>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); },
                                             epi, epix);
         }
         __syncthreads();
@@ -548,7 +588,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 if (C::DUP && half && i == 0) return;                           // ... and stored by the first half only
                 *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
             };
-            gemm_tiles<F64, 2>(wb, LAY.l3_w[blk], nt, mt0, pre, afrag, [&]() {
+            gemm_tiles<F64, 2, CCSP_NET_SEG_L3>(wb, LAY.l3_w[blk], nt, mt0, pre, afrag, [&]() {
                 if (blk < 8) prefetch<4>(wb, LAY.l1_w[blk < 8 ? blk + 1 : 8], nt2, pre);
                 else prefetch<4>(wb, LAY.pc_w, 0, pre);
             }, epi);
@@ -568,7 +608,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         auto epi = [&](int mt, const f32x4 &acc, int i) {
             *reinterpret_cast<f32x4 *>(&pc[(mt * 16 + l15) * 16 + 4 * q]) = relu4(acc + bv);
         };
-        gemm_tiles<2, 4>(wb, LAY.pc_w, 0, mt0, pre, afrag, []() {}, epi);
+        gemm_tiles<2, 4, CCSP_NET_SEG_PC>(wb, LAY.pc_w, 0, mt0, pre, afrag, []() {}, epi);
     }
     // ---- value head, part 1: 1x1 64 -> 1 (+ReLU) per row, into y2[0..199] -----------------------------
     float *vc = S.y2;                                    // [200]

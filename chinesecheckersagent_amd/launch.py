@@ -29,10 +29,14 @@ def rank_env(rank, world, port, device=None, extra=None):
     return env
 
 
-def run_ranks(argv, world, devices=None, extra_env=None, poll=0.2, timeout=None):
+KILL_GRACE_S = 15.0      # seconds between SIGTERM and SIGKILL for ranks that do not leave (wedged in a kernel or a collective)
+
+
+def run_ranks(argv, world, devices=None, extra_env=None, poll=0.2, timeout=None, kill_grace=None):
     """start `world` copies of `argv` (a full command line) as ranks 0..world-1; devices[r] = the HIP device of rank r
     (default r; [0, 0] puts two ranks on one device for functional tests).  Returns 0, or the first failing rank's exit
-    code after terminating the rest."""
+    code after terminating the rest (124 when `timeout` seconds passed first); ranks that ignore the SIGTERM are killed
+    `kill_grace` seconds later, so the caller always gets an answer."""
     port = free_port()
     procs = []
     for r in range(world):
@@ -41,6 +45,8 @@ def run_ranks(argv, world, devices=None, extra_env=None, poll=0.2, timeout=None)
     rc = 0
     alive = list(procs)
     t0 = time.time()
+    t_kill = None
+    grace = KILL_GRACE_S if kill_grace is None else float(kill_grace)
     while alive:
         time.sleep(poll)
         for p in list(alive):
@@ -52,11 +58,16 @@ def run_ranks(argv, world, devices=None, extra_env=None, poll=0.2, timeout=None)
                 rc = code if code > 0 else 1
                 for q in alive:
                     q.terminate()
-        if timeout is not None and alive and time.time() - t0 > timeout:
-            rc = rc or 124
+                t_kill = time.time() + grace
+        if timeout is not None and alive and rc == 0 and time.time() - t0 > timeout:
+            rc = 124
             for q in alive:
                 q.terminate()
-            timeout = None
+            t_kill = time.time() + grace
+        if t_kill is not None and alive and time.time() > t_kill:
+            for q in alive:
+                q.kill()
+            t_kill = None
     if rc:
         sys.stderr.write('chinesecheckersagent_amd.launch: a rank process failed (exit code %d)\n' % rc)
     return rc

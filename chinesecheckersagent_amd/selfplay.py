@@ -677,13 +677,15 @@ def generate_self_play(worker_id, model_path, num_self_play, model2_path=None, s
 
 def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model2_path=None, sims=MCTS_SIMULATIONS, seed=None,
                                    first_game=None, randomised=False, devices=None, as_arrays=False, out_dir=None, max_slots=MAX_SLOTS,
-                                   return_summary=False):
+                                   return_summary=False, timeout=None):
     """train.generate_self_play_in_parallel (train.py:71-105) with GPUs for workers: `num_workers` rank processes, one per
     MI355X (devices[r], default r), are started from THIS process -- which never touches the GPU -- and play the ids
     first_game + j, j < num_self_play, sharded j mod num_workers; their counters and visit histograms meet in one RCCL
     all-reduce.  Returns the reference's list [(play_history, p1_reward)] of the games that were not discarded, in game-id
     order (as_arrays=True: utils.convert_to_train_data of that list as (board_x, pi_y, v_y) arrays, no object per position);
-    with return_summary=True also the all-reduced summary {'counters': ..., 'visit_histogram': ...}."""
+    with return_summary=True also the all-reduced summary {'counters': ..., 'visit_histogram': ...}.
+    timeout (seconds): ranks still running after it are terminated (then killed) and the call raises, instead of waiting for ever on
+    a rank that stalls in a collective or a wedged kernel."""
     import json
     import os
     import sys
@@ -710,9 +712,9 @@ def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model
                                                ([os.environ['PYTHONPATH']] if os.environ.get('PYTHONPATH') else []))}
         if devices is not None and len(set(devices)) < len(devices):
             extra['CCSP_ONE_DEVICE'] = '1'                 # several ranks on one device: gloo carries the summary
-        rc = launch.run_ranks(argv, num_workers, devices=devices, extra_env=extra)
+        rc = launch.run_ranks(argv, num_workers, devices=devices, extra_env=extra, timeout=timeout)
         if rc:
-            raise _lib.CcspError('generate_self_play_in_parallel: a rank process failed (exit code %d)' % rc)
+            raise _lib.CcspError('generate_self_play_in_parallel: %s' % ('timed out after %s s' % timeout if rc == 124 else 'a rank process failed (exit code %d)' % rc))
         results = np.zeros(num_self_play, dtype=_lib.RESULT_DTYPE)
         results['status'] = 0xFF
         rows = []

@@ -245,24 +245,36 @@ class Trainer(object):
         quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
         if quiet is not None:
             quiet(False)                               # (the warm-up runs on a side stream on purpose)
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                self.step(self._gx, self._gpi, self._gz)
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            self.net.load_state_dict(keep)
-            for p_, st in self.opt.state.items():
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        v.copy_(opt_keep[id(p_)][k]) if had_state else v.zero_()
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self.step(self._gx, self._gpi, self._gz)
+        except BaseException:
+            if quiet is not None:
+                quiet(True)
+            raise
+        finally:
+            # whatever happened to the throw-away steps (all-zero batch), training starts from the weights that were loaded: the eager
+            # fallback of fit() must not inherit them
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.no_grad():
+                self.net.load_state_dict(keep)
+                for p_, st in self.opt.state.items():
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(opt_keep[id(p_)][k]) if (had_state and id(p_) in opt_keep and k in opt_keep[id(p_)]) else v.zero_()
         self.net.train()
-        g = torch.cuda.CUDAGraph()
-        self.opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g):
-            logits, v = self.net(self._gx)
-            total, policy, value, reg = self.loss(logits, v, self._gpi, self._gz)
-            total.backward()
-            self.opt.step()
+        try:
+            g = torch.cuda.CUDAGraph()
+            self.opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                logits, v = self.net(self._gx)
+                total, policy, value, reg = self.loss(logits, v, self._gpi, self._gz)
+                total.backward()
+                self.opt.step()
+        finally:
+            if quiet is not None:
+                quiet(True)                            # the warning is back on whether the capture worked or not
         self._graph, self._graph_loss, self._graph_bs = g, total, batch_size
 
     def fit(self, board_x, pi_y, v_y, batch_size=BATCH_SIZE, epochs=EPOCHS, validation_split=0.05, seed=0, use_graph=True):
@@ -482,7 +494,11 @@ def evolve(cur_model_path, other_opponent_for_selfplay=None, iteration_count=0, 
     if rank != 0:
         log = lambda *a, **k: None                                      # noqa: E731
     done = 0
-    game0 = 0
+    # game ids (= draw streams) of an iteration follow from its NUMBER: a run that is re-invoked at iteration k (the CLI resumes with
+    # iteration_count = version + 1) with an unchanged self-play model -- e.g. the best model kept after a rejected gate -- would
+    # otherwise replay iteration 0's ids bit for bit and pool duplicates of its games with the previous iteration's data.  (The
+    # reference reseeds every worker from OS entropy, train.py:38-39.)
+    game0 = iteration_count * (num_self_play + eval_games)
     while iterations is None or done < iterations:
         tm = {'iteration': iteration_count}
         t0 = time.time()
@@ -560,9 +576,10 @@ def evolve_rank(config_path):
         dist.destroy_process_group()
 
 
-def evolve_in_parallel(n_gpus, cur_model_path, devices=None, work_dir=None, **kw):
+def evolve_in_parallel(n_gpus, cur_model_path, devices=None, work_dir=None, timeout=None, **kw):
     """train.evolve over `n_gpus` MI355X (BASELINE config 5): starts one rank process per GPU from THIS process, which never
-    touches the GPU, and returns (cur_model_path, best_model, iteration_count, timings) of the run.  kw = evolve()'s arguments."""
+    touches the GPU, and returns (cur_model_path, best_model, iteration_count, timings) of the run.  kw = evolve()'s arguments.
+    timeout (seconds): ranks still running after it are terminated (then killed) and the call raises."""
     import json
     import sys
     import tempfile
@@ -583,9 +600,9 @@ def evolve_in_parallel(n_gpus, cur_model_path, devices=None, work_dir=None, **kw
         if devices is not None and len(set(devices)) < len(devices):
             extra['CCSP_ONE_DEVICE'] = '1'
         rc = launch.run_ranks([sys.executable, '-m', 'chinesecheckersagent_amd.worker', 'evolve', '--config', cfg], n_gpus,
-                              devices=devices, extra_env=extra)
+                              devices=devices, extra_env=extra, timeout=timeout)
         if rc:
-            raise RuntimeError('evolve_in_parallel: a rank process failed (exit code %d)' % rc)
+            raise RuntimeError('evolve_in_parallel: %s' % ('timed out after %s s' % timeout if rc == 124 else 'a rank process failed (exit code %d)' % rc))
         r = json.load(open(result))
         return r['cur_model_path'], r['best_model'], r['iteration_count'], r['timings']
     finally:

@@ -635,6 +635,8 @@ static int make_move_ex(const board_t *root_state, int player, uint64_t seed, ui
         for (int i = 0; i < k; i++) {
             edge_t *e = &t.edges[t.nodes[root].first_edge + i];
             pi[e->id * NCELL + e->dest] = pow((double)e->N, inv_tau);
+            /* Python's pow(int, float) raises OverflowError where the result leaves float64 (N >= 1210 at tau = 0.01) */
+            if (pi[e->id * NCELL + e->dest] > 1.7976931348623157e308) { rc = -3; goto done; }
         }
         double s = pairwise_sum(pi, NACT);                                       /* MCTS.py:137 */
         for (int i = 0; i < NACT; i++) pi[i] /= s;

@@ -711,3 +711,63 @@ GREEDY_EXTRA = [(20178, True, False), (22641, True, False)]
 
 if __name__ == '__main__' and 'greedy' in sys.argv[1:]:
     gen_greedy()
+
+
+# ---- round 4: the statistics game.py records (game.py:103-119) -----------------------------------------------------------
+# 10 000 Game.start games "greedy against GreedyPlayer(stochastic=True)": Counter({1: 5172, 2: 4675, None: 153}) /
+# Counter({1: 5233, 2: 4594, None: 173}).  The reference's CURRENT stochastic policy (player.py:77-97: a forward move drawn with
+# probability proportional to its distance) cannot produce those figures -- it loses nine games in ten to the deterministic
+# player -- while two deterministic players do.  This generator plays the imported reference itself, every seating, on the
+# substituted draws: per game (winner, number of moves), so that the oracle and the GPU must reproduce every game AND the
+# frequencies, and the record in game.py can be compared with what the reference's own code does today.
+STATS_FIRST, STATS_N = 30000, 10000
+
+
+def _stats_job(job):
+    seating, first, n = job
+    from refenv import ref_game, ref_player
+    orig_gr = ref_player.GreedyPlayer.decide_move
+    out = []
+    for game in range(first, first + n):
+        ctx.seed, ctx.game = SEED, game
+        count = [0]
+
+        def decide(self, board, verbose=False, training=False, total_moves=None):
+            ctx.ply = total_moves
+            count[0] += 1
+            return orig_gr(self, board, verbose=verbose, total_moves=total_moves)
+        ref_player.GreedyPlayer.decide_move = decide
+        try:
+            with quiet():
+                gm = ref_game.Game(p1_type='g', p2_type='g', verbose=False)
+                if seating[0] == 's':
+                    gm.player_one = ref_player.GreedyPlayer(player_num=1, stochastic=True)
+                if seating[1] == 's':
+                    gm.player_two = ref_player.GreedyPlayer(player_num=2, stochastic=True)       # game.py:111
+                gm.cur_player, gm.next_player = gm.player_one, gm.player_two
+                winner = gm.start()
+        finally:
+            ref_player.GreedyPlayer.decide_move = orig_gr
+        out.append([winner or 0, count[0]])
+    return out
+
+
+def gen_greedy_stats():
+    from multiprocessing import Pool
+    t0 = time.time()
+    doc = dict(seed=SEED, first_game=STATS_FIRST, n=STATS_N, seatings={},
+               record_in_game_py=[{'1': 5172, '2': 4675, 'None': 153}, {'1': 5233, '2': 4594, 'None': 173}])
+    chunk = 125
+    with Pool(8) as pool:
+        for seating in ('gg', 'gs', 'sg'):
+            parts = pool.map(_stats_job, [(seating, STATS_FIRST + i, chunk) for i in range(0, STATS_N, chunk)], chunksize=1)
+            rows = [r for p in parts for r in p]
+            c = {w: sum(1 for r in rows if r[0] == w) for w in (1, 2, 0)}
+            doc['seatings'][seating] = dict(winner=[r[0] for r in rows], moves=[r[1] for r in rows], counts={'1': c[1], '2': c[2], 'None': c[0]})
+            print('greedy stats %s: %s  %.0fs' % (seating, doc['seatings'][seating]['counts'], time.time() - t0), file=sys.stderr)
+    with open(os.path.join(OUT, 'greedy_stats.json'), 'w') as f:
+        json.dump(doc, f, separators=(',', ':'))
+
+
+if __name__ == '__main__' and 'greedy_stats' in sys.argv[1:]:
+    gen_greedy_stats()

@@ -364,6 +364,30 @@ def test_restarting_slots_return_the_records_of_one_slot_per_game(golden_dir, tm
     assert key(fx, fp, fv) == key(bx, py, vy)
 
 
+def test_randomised_two_model_games_at_1024_restarting_slots(golden_dir):
+    """`randomised=True` two-model games (selfplay.py:11-17, 76-78; board.py:61-85) in the delivered mode at a real batch size:
+    1536 game ids through 1024 restarting slots (every third slot plays a second game), harvested every 4 plies, against one slot
+    per game -- every game's status, reward, searched positions and pi"""
+    from chinesecheckersagent_amd import selfplay as sp
+    from chinesecheckersagent_amd.model import ResidualCNN
+    m1, m2 = ResidualCNN(), ResidualCNN()
+    m1.load_weights(golden_dir + '/good_model.h5')
+    m2.load_weights(golden_dir + '/good_model2.h5')
+    n, sims, seed, first = 1536, 6, 23, 5000
+    b = sp.BatchSelfPlay(m1, m2, n_slots=n, sims=sims, seed=seed, first_game=first, max_games=n, randomised=True, log_capacity=n * 700)
+    want = _records(b.run_to_completion(max_plies=1100))
+    b.close()
+    assert all(h != 'unfinished' for h, _ in want) and any(h is None for h, _ in want) and sum(isinstance(h, list) for h, _ in want) > n // 2
+    run = sp.SelfPlayRun(m1, m2, n_games=n, sims=sims, seed=seed, first_game=first, randomised=True, max_slots=1024, harvest_every=4)
+    got = _records(run.run().games())
+    c = run.counters()
+    run.close()
+    assert c['errors'] == 0 and c['games_won'] + c['games_discarded'] == n
+    assert len(got) == len(want) == n
+    for k, (a, w) in enumerate(zip(got, want)):
+        assert a == w, 'game %d differs' % (first + k)
+
+
 def test_config1_one_whole_game_50_sims_matches_oracle(golden_dir):
     """BASELINE config 1 for real (selfplay.py:155-175): ONE whole game at 50 simulations per move with good_model.h5 through
     the delivered selfplay() on the HIP path, against the CPU oracle playing the same game id with a callback into the same
@@ -495,7 +519,13 @@ def test_bench_launcher_world2_on_one_device(tmp_path):
     one = _bench(['--gpus', '1', '--games', '64', '--no-config5', '--cpu-seconds', '0'])
     assert two['n_gpus'] == 2 and one['n_gpus'] == 1 and one['cpu_baseline'] is None and 'config5' not in one
     for doc in (one, two):
-        assert doc['steps'] == 3 and doc['errors'] == 0 and doc['backend'] == 'hip' and doc['value'] > 0
+        assert doc['steps'] == 3 and doc['errors'] == 0 and doc['backend'] == 'hip' and doc['value'] > 0 and doc['degraded'] is False
+        # what the driver's record keeps: BASELINE's games/s and the run's description inside `config`, the isolated figure beside the
+        # delivered one in `roofline`, host CPU seconds and peak RSS of every rank
+        ms = doc['config']['measured']
+        assert ms['games_per_s'] >= 0 and 0 <= ms['discard_rate'] <= 1 and ms['timed_region_s_total'] > 0 and ms['node_expansions_per_s'] == doc['value']
+        assert len(ms['host_cpu_s_per_rank']) == len(ms['host_peak_rss_mb_per_rank']) == doc['n_gpus'] and min(ms['host_peak_rss_mb_per_rank']) > 100
+        assert 0 < doc['roofline']['frac'] <= doc['roofline']['frac_isolated'] * 1.05 and doc['roofline']['avg_launch_ms_isolated'] > 0
         assert doc['roofline']['bound'] == 'mfma' and 0 < doc['roofline']['frac'] < 1
         v2a = doc['variants']['2a_fused_table_evaluator']
         assert v2a['errors'] == 0 and v2a['roofline']['bound'] == 'latency/issue'
@@ -521,6 +551,14 @@ def test_bench_survives_a_rank_that_never_joins_config5():
                  CCSP_BENCH_TEST_STALL_RANK='1')
     assert two['n_gpus'] == 2 and two['value'] > 0 and two['errors'] == 0 and 'watchdog' in two['config5']['failed']
     assert two['variants']['2a_fused_table_evaluator']['node_expansions_per_s'] > 0
+    assert two['degraded'] is True and 'config 5' in two['degraded_reason']      # the record is not silently clean
+    # a rank whose config 5 RAISES: the others leave within a second or two of its flag file, not after the timeout
+    import time
+    t0 = time.time()
+    two = _bench(['--gpus', '2', '--games', '32', '--config5-timeout', '600', '--cpu-seconds', '0'], CCSP_BENCH_ONE_DEVICE='1',
+                 CCSP_BENCH_TEST_FAIL_RANK='1')
+    assert time.time() - t0 < 300
+    assert two['degraded'] is True and two['value'] > 0 and 'failed' in two['config5'] and two['cpu_baseline'] is None
 
 
 def test_bench_summary_collectives_through_rccl_world1():

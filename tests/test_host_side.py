@@ -290,3 +290,22 @@ def test_parallel_generator_fails_loudly_without_a_gpu(tmp_path):
     with pytest.raises(RuntimeError, match='rank process failed'):
         tr.evolve_in_parallel(2, w, iterations=1, num_self_play=2, eval_games=2, sims=4, seed=1, work_dir=str(tmp_path),
                               data_dir=str(tmp_path / 'd'), weights_dir=str(tmp_path / 'w'))
+
+
+def test_run_ranks_times_out_and_kills_a_rank_that_ignores_sigterm():
+    """launch.run_ranks: a rank that stalls without exiting (a blocked collective, a wedged kernel) must not hang the caller for ever:
+    after `timeout` the ranks get SIGTERM, after `kill_grace` more seconds SIGKILL, and the caller gets 124; a rank that fails makes
+    the others leave the same way"""
+    import time
+    from chinesecheckersagent_amd import launch
+    stubborn = [sys.executable, '-c',
+                'import signal, time, os\n'
+                'signal.signal(signal.SIGTERM, signal.SIG_IGN)\n'
+                'time.sleep(0.3 if os.environ["RANK"] == "1" and os.environ.get("FAIL_ONE") else 600)\n'
+                'raise SystemExit(7 if os.environ.get("FAIL_ONE") else 0)\n']
+    t0 = time.time()
+    assert launch.run_ranks(stubborn, 2, timeout=1.0, kill_grace=1.0, poll=0.05) == 124
+    assert time.time() - t0 < 20
+    t0 = time.time()
+    assert launch.run_ranks(stubborn, 2, extra_env={'FAIL_ONE': '1'}, kill_grace=1.0, poll=0.05) == 7
+    assert time.time() - t0 < 20

@@ -11,13 +11,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 
-LOGIT_TOL = 1e-5        # absolute, on logits in [-11, 17] (BASELINE.json north_star)
-# DEVIATION from north_star, stated in DESIGN.md section 5: a float32 evaluation (the reference's own Keras floatx) of
-# this 30-layer net differs from a float64 one by more than 1e-5 on a few logits in 10^4 whatever computes it -- the
-# float32 NumPy restatement (oracle/net_oracle.py, dtype=float32): 24 of 75 264 logits, max 2.1e-5; the fused HIP
-# kernel: 4 of 75 264, max 1.1e-5; mean 7e-7 / 9e-7.  So: fp64 mode meets 1e-5 outright (it meets 1e-9); fp32 modes
-# are held to >= 99.9 % of logits within 1e-5 and ALL within the cap below, and to being no further from the float64
-# vectors than the float32 restatement is (test_float32_distances).
+LOGIT_TOL = 1e-5        # absolute, on logits in [-15, 23] (BASELINE.json north_star)
+# DEVIATION from north_star, stated in DESIGN.md section 5 and set FROM EVIDENCE (round 4): a float32 evaluation (the reference's own
+# Keras floatx) of this 30-layer net differs from a float64 one by more than 1e-5 on a few logits in 10^5 whatever computes it.
+# Measured on the widened fixture -- 4096 self-play positions x the reference's three weight files = 3 612 672 logits
+# (profiles/r4_n1_wide.json): the fused HIP kernel max 2.19e-5, 82 logits >= 1e-5 (2.3e-5 of all), 99.99th percentile 8.7e-6 / 7.5e-6 /
+# 4.5e-6 per weight file, mean 5.6e-7 / 7.5e-7 / 2.9e-7.  The bars: every logit within 1.25 x the measured maximum, >= 99.99 % within
+# 1e-5; values within 1e-5 outright; fp64 mode 1e-9.  On the 256-position fixture (75 264 logits) the kernel's maximum is 1.26e-5:
+# cap 1.25 x that.  The float32 evaluators that are NOT the product path (the PyTorch module on the CPU / through MIOpen, the float32
+# NumPy restatement: max 2.1e-5 on the small fixture) keep the loose cap.
+FP32_CAP_WIDE, FP32_FRACTION_WIDE = 2.75e-5, 0.9999
+FP32_CAP_HIP_SMALL = 1.6e-5
 FP32_FRACTION, FP32_CAP = 0.999, 3e-5
 
 
@@ -40,7 +44,8 @@ def _check(model, net, name, n):
     if model.precision == 'fp64':
         assert d.max() < 1e-9 and np.abs(v - net['v_' + name][:n]).max() < 1e-9
     else:
-        assert (d < LOGIT_TOL).mean() >= FP32_FRACTION and d.max() < FP32_CAP, (d.max(), (d < LOGIT_TOL).mean())
+        cap = FP32_CAP_HIP_SMALL if getattr(model, 'backend', '') == 'hip' else FP32_CAP
+        assert (d < LOGIT_TOL).mean() >= FP32_FRACTION and d.max() < cap, (d.max(), (d < LOGIT_TOL).mean())
         assert np.abs(v - net['v_' + name][:n]).max() < LOGIT_TOL
     p, _ = model.evaluate_batch(x)
     import net_oracle
@@ -60,12 +65,12 @@ def test_cpu_forward_matches_float64_restatement(net, golden_dir):
     assert abs(p.sum() - 1) < 1e-12
 
 
-@pytest.mark.skipif(not os.path.exists('/root/reference/good_model2.h5'), reason='reference tree not present (GPU box)')
-def test_other_weight_files(net):
+def test_other_weight_files(net, golden_dir):
+    """the reference's other two weight files (data fixtures since round 4) through the CPU module"""
     from chinesecheckersagent_amd.model import ResidualCNN
     for name in ('good_model2', 'version0016-weights'):
         m = ResidualCNN(device='cpu')
-        m.load_weights('/root/reference/%s.h5' % name)
+        m.load_weights(golden_dir + '/%s.h5' % name)
         _check(m, net, name, 32)
 
 
@@ -245,14 +250,14 @@ def test_gpu_evaluation_is_a_function_of_the_position_alone(net, golden_dir):
                     for r in rows:
                         assert torch.equal(lg[r], want[k][0]) and torch.equal(v[r], want[k][1]) and torch.equal(p[r], want[k][2]), (shape, n, int(r))
             d = np.abs(torch.stack([w[0] for w in want]).double().cpu().numpy() - ref64)
-            assert d.max() < FP32_CAP
+            assert d.max() < FP32_CAP_HIP_SMALL
     finally:
         L.ccsp_debug_net_shape(0)
 
 
 @pytest.mark.gpu
 def test_gpu_float32_distances(net, golden_dir):
-    """the fused HIP kernel against the float64 AND the float32 restatements, numbers written out for DESIGN.md"""
+    """the fused HIP kernel against the float64 AND the float32 restatements"""
     import json
     import torch
     from chinesecheckersagent_amd.model import ResidualCNN
@@ -265,11 +270,11 @@ def test_gpu_float32_distances(net, golden_dir):
     doc = {'hip_fp32_vs_fp64_restatement': _dist(lh, ref64), 'hip_fp32_vs_fp32_restatement': _dist(lh, l32),
            'fp32_restatement_vs_fp64_restatement': _dist(l32, ref64),
            'v_hip_vs_fp64': _dist(vh, net['v_good_model'][:256]), 'north_star_tolerance': LOGIT_TOL, 'logits': int(lh.size)}
-    out = os.path.join(ROOT, 'gpurun_out')
-    os.makedirs(out, exist_ok=True)
-    json.dump(doc, open(os.path.join(out, 'n1_parity.json'), 'w'), indent=1)
-    for k in ('hip_fp32_vs_fp64_restatement', 'hip_fp32_vs_fp32_restatement'):
-        assert doc[k]['frac_within_1e-5'] >= FP32_FRACTION and doc[k]['max'] < FP32_CAP and doc[k]['mean'] < 2e-6, doc
+    print('N1 small fixture: ' + json.dumps(doc))          # (tools/n1_wide.py writes the numbers kept under profiles/)
+    k = 'hip_fp32_vs_fp64_restatement'
+    assert doc[k]['frac_within_1e-5'] >= FP32_FRACTION and doc[k]['max'] < FP32_CAP_HIP_SMALL and doc[k]['mean'] < 1e-6, doc
+    k = 'hip_fp32_vs_fp32_restatement'                     # two float32 evaluations of different order: the loose cap
+    assert doc[k]['frac_within_1e-5'] >= FP32_FRACTION and doc[k]['max'] < FP32_CAP and doc[k]['mean'] < 2e-6, doc
     assert doc['v_hip_vs_fp64']['max'] < LOGIT_TOL
     assert doc['hip_fp32_vs_fp64_restatement']['max'] <= 1.5 * doc['fp32_restatement_vs_fp64_restatement']['max']
 
@@ -292,3 +297,133 @@ def test_against_keras_vectors_when_present(net, golden_dir):
     assert d['frac_within_1e-5'] >= FP32_FRACTION and d['max'] < FP32_CAP, d
     assert _dist(net['logits_good_model'][:256], k['logits_good_model'][:256])['max'] < FP32_CAP     # the float64 oracle itself
     assert np.abs(vp.cpu().numpy() - k['v_good_model'][:256]).max() < LOGIT_TOL
+
+
+# ---- round 4: the widened fixture (tests/golden/net_wide.npz) ------------------------------------------------------------------
+
+def _unfolded_torch_float64(weights, planes):
+    """THIRD derivation of the graph, sharing no code with oracle/net_oracle.py or with the product's BatchNorm folding:
+    torch.nn.functional.conv2d (cross-correlation, NCHW / OIHW) + F.batch_norm(eps=1e-3) as its own step, float64, CPU"""
+    import torch
+    import torch.nn.functional as F
+
+    def t(layer, name):
+        return torch.from_numpy(np.asarray(weights['%s/%s/%s:0' % (layer, layer, name)], dtype=np.float64))
+
+    def conv_bn(x, i, pad):
+        y = F.conv2d(x, t('conv2d_%d' % i, 'kernel').permute(3, 2, 0, 1).contiguous(), t('conv2d_%d' % i, 'bias'), padding=pad)
+        bn = 'batch_normalization_%d' % i
+        return F.batch_norm(y, t(bn, 'moving_mean'), t(bn, 'moving_variance'), t(bn, 'gamma'), t(bn, 'beta'), training=False, eps=1e-3)
+    x = torch.from_numpy(np.asarray(planes, dtype=np.float64)).permute(0, 3, 1, 2).contiguous()
+    x = F.relu(conv_bn(x, 1, 0))
+    i = 2
+    for _ in range(9):
+        y = F.relu(conv_bn(x, i, 0))
+        y = F.relu(conv_bn(y, i + 1, 1))
+        x = F.relu(conv_bn(y, i + 2, 0) + x)
+        i += 3
+    p = F.relu(conv_bn(x, 29, 0)).permute(0, 2, 3, 1).reshape(len(x), -1)            # Keras Flatten of an NHWC tensor
+    logits = p @ t('policy_head', 'kernel') + t('policy_head', 'bias')
+    v = F.relu(conv_bn(x, 30, 0)).permute(0, 2, 3, 1).reshape(len(x), -1)
+    v = torch.tanh(F.relu(v @ t('dense_1', 'kernel') + t('dense_1', 'bias')) @ t('value_head', 'kernel') + t('value_head', 'bias'))
+    return logits.numpy(), v[:, 0].numpy()
+
+
+def test_wide_fixture_three_derivations_agree(golden_dir):
+    """the float64 restatement recomputed here (weights through h5lite) lands on the fixture (made with h5py in the build container) on
+    the 512-position subset for all three weight files, and the unfolded torch derivation lands on it too"""
+    import net_wide_ref
+    from chinesecheckersagent_amd.model import read_keras_weights
+    z = net_wide_ref.fixture()
+    assert z['planes'].shape == (4096, 343) and len(np.unique(z['planes'], axis=0)) == 4096
+    assert set(np.unique(z['player'])) == {1, 2} and z['ply'].max() > 100 and set(np.unique(z['kind'])) == {0, 1, 2}
+    import oracle_ffi as orc
+    for i in (0, 1, 777, 4095):                                # the stored planes are the planes of the stored positions
+        assert np.array_equal(orc.planes(z['pos12'][i], z['last'][i], int(z['player'][i])), z['planes'][i])
+    ref = net_wide_ref.reference_logits(subset_only=True)       # (asserts 1e-11 against the fixture's vectors)
+    x = z['planes'][z['sub']].reshape(-1, 7, 7, 7)
+    for name in net_wide_ref.NAMES:
+        lg, v = _unfolded_torch_float64(read_keras_weights(golden_dir + '/%s.h5' % name), x)
+        assert np.abs(lg - z['logits_' + name]).max() < 1e-9 and np.abs(v - z['v_' + name]).max() < 1e-10, name
+        assert np.abs(lg - ref['logits_' + name]).max() < 1e-9
+
+
+def test_policy_mass_on_legal_moves_whole_fixture():
+    """semantic check of the graph reading over ALL 4096 positions and all three weight files: the softmax mass on the position's
+    legal moves (fixture: legal_mass_<name>, computed by the restatement) is several times what an unrelated reading gives --
+    a wrong flatten order, a transposed board or a wrong action codec all land on chance = (legal moves) / 294"""
+    import net_oracle
+    import net_wide_ref
+    import oracle_ffi as orc
+    from chinesecheckersagent_amd.model import read_keras_weights
+    z = net_wide_ref.fixture()
+    sub = z['sub']
+    legal = [np.array([int(a) * 49 + int(b) for a, b in orc.movegen(z['pos12'][i], int(z['player'][i]))]) for i in sub]
+    chance = float(np.mean([len(l) for l in legal])) / 294.0
+    assert 0.08 < chance < 0.2
+    for name, floor in (('good_model', 0.33), ('good_model2', 0.25), ('version0016-weights', 0.32)):
+        mass = z['legal_mass_' + name]
+        assert mass.shape == (4096,) and mass.mean() > floor and mass.mean() > 2.2 * chance, (name, mass.mean(), chance)
+        # the stored masses are those of the stored logits (subset), with the legal moves generated here
+        p = net_oracle.softmax64(z['logits_' + name])
+        here = np.array([p[k, legal[k]].sum() for k in range(len(sub))])
+        assert np.abs(here - mass[sub]).max() < 1e-12
+        # an unrelated reading of the same numbers: action index read as id * 49 + col * 7 + row -> chance
+        pt = p.reshape(-1, 6, 7, 7).transpose(0, 1, 3, 2).reshape(-1, 294)
+        wrong = np.array([pt[k, legal[k]].sum() for k in range(len(sub))])
+        assert wrong.mean() < 1.5 * chance < here.mean()
+    # (c, h, w) flatten order in front of the policy dense layer instead of Keras' (h, w, c): chance
+    w = read_keras_weights(os.path.join(net_wide_ref.GOLD, 'good_model.h5'))
+    x = z['planes'][sub[:128]].reshape(-1, 7, 7, 7).astype(np.float64)
+    net_oracle._DT[0] = np.float64
+    t = np.maximum(net_oracle.conv_bn(x, w, 1, 'valid'), 0.0)
+    i = 2
+    for _ in range(9):
+        y = np.maximum(net_oracle.conv_bn(t, w, i, 'valid'), 0.0)
+        y = np.maximum(net_oracle.conv_bn(y, w, i + 1, 'same'), 0.0)
+        t = np.maximum(net_oracle.conv_bn(y, w, i + 2, 'valid') + t, 0.0)
+        i += 3
+    pc = np.maximum(net_oracle.conv_bn(t, w, 29, 'valid'), 0.0)
+    K, b = net_oracle._w(w, 'policy_head', 'kernel'), net_oracle._w(w, 'policy_head', 'bias')
+    good = net_oracle.softmax64(pc.reshape(len(pc), -1) @ K + b)
+    bad = net_oracle.softmax64(pc.transpose(0, 3, 1, 2).reshape(len(pc), -1) @ K + b)
+    m_good = np.mean([good[k, legal[k]].sum() for k in range(128)])
+    m_bad = np.mean([bad[k, legal[k]].sum() for k in range(128)])
+    assert m_bad < 1.6 * chance and m_good > 2.2 * chance, (m_good, m_bad, chance)
+
+
+@pytest.mark.gpu
+def test_gpu_all_three_weight_files_on_the_wide_fixture(golden_dir):
+    """the fused HIP kernel on 4096 self-play positions x the reference's three weight files = 3 612 672 logits against the float64
+    restatement (recomputed here, held to the fixture's digests): the bars are set from the measured distances (header)"""
+    import torch
+    import net_wide_ref
+    from chinesecheckersagent_amd.model import ResidualCNN
+    z = net_wide_ref.fixture()
+    ref = net_wide_ref.reference_logits(cache='/tmp/n1_wide_ref.npz')
+    x = torch.from_numpy(z['planes'].reshape(-1, 7, 7, 7).astype(np.float32)).cuda()
+    above = total = 0
+    for name in net_wide_ref.NAMES:
+        m = ResidualCNN(device='cuda', backend='hip')
+        m.load_weights(golden_dir + '/%s.h5' % name)
+        assert m.backend == 'hip'
+        lg, v = m.predict_batch(x)
+        d = np.abs(lg.double().cpu().numpy() - ref['logits_' + name])
+        assert d.max() < FP32_CAP_WIDE and (d < LOGIT_TOL).mean() >= FP32_FRACTION_WIDE and d.mean() < 1e-6, (name, d.max(), (d < LOGIT_TOL).mean())
+        assert np.quantile(d, 0.9999) < LOGIT_TOL, name
+        assert np.abs(v.double().cpu().numpy() - ref['v_' + name]).max() < LOGIT_TOL, name
+        above, total = above + int((d >= LOGIT_TOL).sum()), total + d.size
+        p, _ = m.evaluate_batch(x)
+        assert np.abs(p.cpu().numpy() - net_oracle_softmax(ref['logits_' + name])).max() < 1e-5
+        # fp64 mode (PyTorch, float64) meets 1e-9 on the same positions
+        if name == 'good_model2':
+            m64 = ResidualCNN(device='cuda', precision='fp64', backend='torch')
+            m64.load_weights(golden_dir + '/%s.h5' % name)
+            l64, _ = m64.predict_batch(x[:1024])
+            assert np.abs(l64.cpu().numpy() - ref['logits_' + name][:1024]).max() < 1e-9
+    assert above / total < 5e-5
+
+
+def net_oracle_softmax(logits):
+    import net_oracle
+    return net_oracle.softmax64(logits)

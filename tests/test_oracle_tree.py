@@ -200,3 +200,24 @@ def test_stochastic_greedy_player_against_the_reference(golden_dir):
         tag = 'stochastic greedy arena game %d' % g['game']
         assert [[int(a), int(b)] for a, b in o['moves']] == g['moves'], tag
         assert (o['winner'] or None) == g['winner'] and o['evals'] == g['evals'], tag
+
+
+def test_pow_overflow_at_det_tau_is_an_error_as_in_the_reference():
+    """MCTS.py:132: pow(N, 1/tau) with tau = 0.01 leaves float64 at N = 1210 and Python raises OverflowError.  Near-win
+    roots under 2000 simulations put more than 1209 visits on one edge: the restatement reports the error instead of
+    pi = inf/inf; with tau = 1, or 1209 simulations, the same search is fine"""
+    seed = 99
+    found = 0
+    for game in range(40):
+        pos = orc.near_win_pos12(seed, game, 1)
+        o = orc.search(pos, orc.NO_LAST, 1, seed, game, 20, 2000, False, 0)
+        if max(o.N[j] for j in range(o.n_root)) < 1210:
+            continue
+        found += 1
+        with pytest.raises(RuntimeError, match='-3'):
+            orc.search(pos, orc.NO_LAST, 1, seed, game, 20, 2000, True, 0)
+        ok = orc.search(pos, orc.NO_LAST, 1, seed, game, 20, 1209, True, 0)
+        assert abs(sum(ok.pi[:]) - 1.0) < 1e-12
+        if found == 3:
+            break
+    assert found == 3
