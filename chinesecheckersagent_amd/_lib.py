@@ -21,7 +21,9 @@ GREEDY_P1, GREEDY_P2, GREEDY_ALTERNATE, GREEDY_RANDOM_START, GREEDY_STOCHASTIC_P
 GREEDY_MAX = 32
 (CNT_EXPANSIONS, CNT_TERMINAL_SIMS, CNT_SIMS, CNT_PLIES, CNT_MCTS_PLIES, CNT_GAMES_WON, CNT_GAMES_DISCARDED,
  CNT_SUM_DEPTH, CNT_SUM_CHILDREN, CNT_SELECT_EDGES, CNT_SAMPLES, CNT_ERRORS) = range(12)
+CNT_CACHE_HITS = 15
 CNT_COUNT = 16
+ADVANCE_REUSE, ADVANCE_LOG_GUARD = 1, 2
 CNT_NAMES = ['expansions', 'terminal_sims', 'sims', 'plies', 'mcts_plies', 'games_won', 'games_discarded',
              'sum_depth', 'sum_children', 'select_edges', 'samples', 'errors']
 
@@ -75,6 +77,9 @@ _SIGS = {
     'ccsp_expand_backup': (C.c_int, [_VP, _VP, _VP, _VP]),
     'ccsp_expand_backup_select': (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     'ccsp_ply_end': (C.c_int, [_VP, _VP]),
+    'ccsp_enable_tree_reuse': (C.c_int, [_VP]),
+    'ccsp_advance': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
+    'ccsp_debug_advance_budget': (C.c_int, [C.c_int]),
     'ccsp_read_counters': (C.c_int, [_VP, _VP]),
     'ccsp_read_visit_histogram': (C.c_int, [_VP, _VP]),
     'ccsp_read_slots': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),

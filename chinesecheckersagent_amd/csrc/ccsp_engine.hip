@@ -12,7 +12,9 @@
 // ply as node blocks, each block = one expanded node:
 //     +0   ccsp_state state (32 B)          the node's position
 //     +32  u32 K, u32 player                edges / player to move
-//     +40  f64 P[K] | f64 W[K] | u32 N[K] | u32 child[K] | u16 mv[K]
+//     +40  u32 shadow, f32 v                tree reuse (ccsp_advance): offset/8 of the SAME position's block in the previous ply's
+//                                           tree (0 = none); the evaluator's value of this position
+//     +48  f64 P[K] | f64 W[K] | u32 N[K] | u32 child[K] | u16 mv[K]
 // child[j] = 0 (leaf not expanded yet) | 0xFFFFFFFF (the move wins: terminal leaf) |
 //            (block offset/8) << 7 | K_child.  A level of selection is therefore ONE round of
 // coalesced loads: lane j reads edge j (and j+64), and the chosen lane's child word already holds
@@ -32,8 +34,9 @@ namespace {
 
 constexpr uint32_t CHILD_LEAF = 0u;
 constexpr uint32_t CHILD_TERMINAL = 0xFFFFFFFFu;
-constexpr int BLOCK_HDR = 40;
-constexpr int MAX_BLOCK_BYTES = (BLOCK_HDR + 26 * CCSP_MAX_MOVES + 7) & ~7;   // 3320
+constexpr int BLOCK_HDR = 48;
+constexpr int MAX_BLOCK_BYTES = (BLOCK_HDR + 26 * CCSP_MAX_MOVES + 7) & ~7;   // 3328
+constexpr int CCSP_EVAL_CACHED = 5;     // internal (ccsp_advance): priors and value copied from the previous ply's tree
 
 // A game slot: 16 x u64 in memory (SlotMem), plain scalars in registers (Slot).  Words:
 //  0-3 root position | 4 game id | 5 draw-stream prefix | 6 result row | 7 expansions
@@ -88,6 +91,7 @@ struct Params {
     SlotMem *slots;
     Pending *pend;
     uint8_t *pool;
+    uint8_t *pool2;               // ccsp_enable_tree_reuse: the second tree pool (a ply is searched in one, the previous ply's tree stays in the other)
     uint64_t pool_stride;
     uint64_t *path;
     uint32_t path_stride;
@@ -119,6 +123,13 @@ constexpr int RCP_N = 422;          // reciprocal table entries kept in LDS by t
 struct Lds {                      // per-wave scratch (one wave per workgroup)
     ccsp_line_tables T;           // line tables (ccsp_rules.h), copied from device constant data
     uint32_t lines[32];           // occupancy pattern of the 27 board lines for the position being expanded
+    uint8_t lists[6][24];
+    uint8_t stack[6][96];         // depth-first stacks of wave_movegen (<= 6 pushes per visited sub-lattice cell)
+    uint8_t cnt[8];
+    uint8_t img[CCSP_PLANES + 1];
+    uint8_t cells[CCSP_NCELL + 7];
+    // LAST: a kernel that neither ends plies nor draws root noise nor divides through the table (advance_kernel) allocates the struct
+    // only up to here (LDS_LIGHT bytes) -- 3.5 KB instead of 6.9: six of its workgroups fit beside an evaluator workgroup, not three
     union {
         struct {                  // ply begin / end: pi vector, Dirichlet draws
             double pi[CCSP_NUM_ACTIONS];
@@ -126,12 +137,8 @@ struct Lds {                      // per-wave scratch (one wave per workgroup)
         };
         double rcp[RCP_N];        // simulation loop: 1/i, i < RCP_N (pick_edge)
     };
-    uint8_t lists[6][24];
-    uint8_t stack[6][96];         // depth-first stacks of wave_movegen (<= 6 pushes per visited sub-lattice cell)
-    uint8_t cnt[8];
-    uint8_t img[CCSP_PLANES + 1];
-    uint8_t cells[CCSP_NCELL + 7];
 };
+constexpr size_t LDS_LIGHT = (offsetof(Lds, pi) + 15) & ~(size_t)15;
 
 struct Tally {                    // wave-uniform counters, flushed once per kernel (named scalars: never indexed)
     unsigned long long expansions, terminal_sims, sims, plies, mcts_plies, games_won, games_discarded,
@@ -323,7 +330,9 @@ __device__ __forceinline__ void move_of(const Lds &lds, int j, int &id, int &des
 struct EvalCtx {
     int kind;
     const double *p_row;          // external: p[slot][294]
-    float v_ext;                  // external: v[slot]
+    float v_ext;                  // external / cached: the position's value (kept in the block header)
+    const double *p_edges;        // cached: P[K] of the same position's block in the previous ply's tree, by edge index
+    uint32_t shadow;              // cached: that block's offset / 8 (kept in the new block's header: its children find theirs through it)
 };
 
 __device__ __forceinline__ double prior_of(const EvalCtx &ev, const ccsp_sr &st, int player, uint64_t key, int id, int dest) {
@@ -392,6 +401,8 @@ __device__ __forceinline__ int wave_expand(Lds &lds, SimCtx &sl, uint8_t *pool, 
         ccsp_store_sr(reinterpret_cast<ccsp_state *>(b), st);
         reinterpret_cast<uint32_t *>(b + 32)[0] = (uint32_t)K;
         reinterpret_cast<uint32_t *>(b + 32)[1] = (uint32_t)player;
+        reinterpret_cast<uint32_t *>(b + 32)[2] = ev.shadow;
+        reinterpret_cast<float *>(b + 32)[3] = ev.v_ext;
     }
     double pr[2] = {0.0, 0.0};
     int idxs[2] = {0, 0};
@@ -403,7 +414,7 @@ __device__ __forceinline__ int wave_expand(Lds &lds, SimCtx &sl, uint8_t *pool, 
             int id, dest;
             move_of(lds, j, id, dest);
             idxs[h] = id * CCSP_NCELL + dest;
-            pr[h] = prior_of(ev, st, player, key, id, dest);
+            pr[h] = ev.kind == CCSP_EVAL_CACHED ? ev.p_edges[j] : prior_of(ev, st, player, key, id, dest);
             // leaf.check_win() after this move (MCTS.py:81, board.py:89-111): only the mover's bitboard changes
             const int from = ccsp_sr_pos(st, (player - 1) * 6 + id);
             const uint64_t flip = (1ULL << from) | (1ULL << dest);
@@ -455,6 +466,8 @@ __device__ __forceinline__ int wave_expand(Lds &lds, SimCtx &sl, uint8_t *pool, 
 struct Leaf {
     int kind;                     // 1 expand, 2 terminal
     int depth;
+    uint32_t parent_shadow;       // SHADOW only: header word "shadow" of the block the last edge leaves from
+    int parent_k, sel;            // that block's edge count and the edge taken
     uint32_t link_off;            // pool offset of the child word of the last edge
     ccsp_sr st;                   // leaf position (kind 1)
     int player;                   // player to move at the leaf
@@ -518,7 +531,7 @@ __device__ __forceinline__ Pick pick_edge(const double *__restrict__ sqrt_tab, c
     return pk;
 }
 
-template <bool RCP, bool REGPATH = RCP>          // RCP: divisions through a table of reciprocals; REGPATH: the caller keeps the path's first 64 levels in registers
+template <bool RCP, bool REGPATH = RCP, bool SHADOW = false>   // RCP: divisions through a table of reciprocals; REGPATH: the caller keeps the path's first 64 levels in registers; SHADOW: tree reuse (ccsp_advance)
 __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab, const double *rcp, const SimCtx &sl, uint8_t *pool, uint64_t *path, uint32_t sim,
                                             uint64_t &mypath, double &myW, uint32_t &myN, uint32_t &select_edges) {
     const int lane = lane_id();
@@ -535,6 +548,8 @@ __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab,
         uint64_t w_sel;
         ccsp_sr st;
         bool have_st = false;
+        uint32_t hdr_shadow = 0;
+        if (SHADOW) hdr_shadow = uni32(reinterpret_cast<const uint32_t *>(b + 32)[2]);   // rides with this level's loads; read at the leaf only
         if (nsum == 0) {
             // First visit of this node: every edge has N = 0, so U = c*P*sqrt(0)/(1+0) = 0 and Q = 0 for all of
             // them -- the running-max rule (MCTS.py:65-69) keeps ALL K edges and random.choice picks uniformly
@@ -564,6 +579,7 @@ __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab,
             continue;
         }
         out.depth = level;
+        out.parent_shadow = hdr_shadow; out.parent_k = K; out.sel = sel;
         out.link_off = off + BLOCK_HDR + 20 * K + 4 * sel;
         out.player = 3 - player;
         // the position is read at the last node of the path only: a load at every level would put a second
@@ -981,7 +997,8 @@ __device__ __forceinline__ double pairwise_294(const double *a) {
 }
 
 // T4 + end of make_move: pi from the root's visit counts, action sampling, sample-log row, Board.place
-__device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot &sl, uint8_t *pool, Tally &tl) {
+// chosen_child (optional): the child word of the root edge that was played (tree reuse: the next ply's root in THIS tree)
+__device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot &sl, uint8_t *pool, Tally &tl, uint32_t *chosen_child = nullptr) {
     const int lane = lane_id();
     const int K = (int)sl.root_k;
     uint8_t *b = pool;
@@ -1025,7 +1042,9 @@ __device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot 
     __syncthreads();
     const int cid = lds.cnt[6], cdest = lds.cnt[7];
     const uint32_t pick_idx = (uint32_t)(cid * CCSP_NCELL + cdest);
-    const bool found = (__ballot(mvs[0] == pick_idx) | __ballot(mvs[1] == pick_idx)) != 0;       // MCTS.py:141-151
+    const uint64_t f_lo = __ballot(mvs[0] == pick_idx), f_hi = __ballot(mvs[1] == pick_idx);
+    const bool found = (f_lo | f_hi) != 0;                                                        // MCTS.py:141-151
+    if (chosen_child && found) *chosen_child = uni32(blk_child(b, K)[f_lo ? ccsp_ctz64(f_lo) : 64 + ccsp_ctz64(f_hi)]);
     // play_history.append((root.state, pi)) (selfplay.py:128) -> one row of the sample log
     unsigned long long row = 0;
     if (lane == 0) row = atomicAdd(P.log_count, 1ULL);
@@ -1132,7 +1151,7 @@ __device__ __forceinline__ void fused_begin_core(const Params &P, Lds &lds, int 
     if (sl.opening_left > 0) wave_opening_ply(P, lds, sl, tl);
     else if (greedy_to_move(P, sl)) wave_greedy_ply(P, lds, sl, tl);
     else {
-        EvalCtx ev; ev.kind = evaluator; ev.p_row = nullptr; ev.v_ext = 0.0f;
+        EvalCtx ev; ev.kind = evaluator; ev.p_row = nullptr; ev.v_ext = 0.0f; ev.p_edges = nullptr; ev.shadow = 0;
         SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = 0; cx.player = sl.player; cx.pool_used = 0; cx.nsum_bias = (uint32_t)P.arena;
         const uint64_t rkey = evaluator == CCSP_EVAL_HASH ? ccsp_state_key(sl.st, (int)sl.player) : 0;
         // (the root's value is backed up along an empty path, selfplay.py:117: nothing to compute)
@@ -1176,7 +1195,7 @@ __device__ __forceinline__ void fused_sims_core(const Params &P, Lds &lds, int g
     const bool use_rcp = P.sims + 2 <= RCP_N;              // every N and 1 + N of this ply indexes the LDS table
     for (int i = lane; i < RCP_N; i += 64) lds.rcp[i] = P.rcp_tab[i];
     __syncthreads();
-    EvalCtx ev; ev.kind = evaluator; ev.p_row = nullptr; ev.v_ext = 0.0f;
+    EvalCtx ev; ev.kind = evaluator; ev.p_row = nullptr; ev.v_ext = 0.0f; ev.p_edges = nullptr; ev.shadow = 0;
     uint32_t n_exp = 0, n_term = 0, sum_depth = 0, sum_children = 0, select_edges = 0;
 #ifdef CCSP_STAMPS            // diagnostic build only (tools/stamps.py): cycles per phase, summed per wave
     unsigned long long t_sel = 0, t_exp = 0, t_bak = 0, t0, t1;
@@ -1300,7 +1319,7 @@ __global__ __launch_bounds__(64) void root_expand_kernel(Params P, const double 
     __syncthreads();
     uint8_t *pool = P.pool + (uint64_t)g * P.pool_stride;
     Tally tl; tally_zero(tl);
-    EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = v[g];
+    EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = v[g]; ev.p_edges = nullptr; ev.shadow = 0;
     SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = 0; cx.player = sl.player; cx.pool_used = 0; cx.nsum_bias = (uint32_t)P.arena;
     sl.sim = (uint32_t)P.arena;                                 // arena: this expansion IS simulation 0
     if (P.arena && sl.ply > CCSP_TOTAL_MOVES_TILL_TAU0) sl.det_tau = 1;
@@ -1364,7 +1383,7 @@ __device__ __forceinline__ void expand_backup_core(const Params &P, Lds &lds, in
     if (pd.kind == 1) {
         ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
         __syncthreads();
-        EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = v[g];
+        EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = v[g]; ev.p_edges = nullptr; ev.shadow = 0;
         val = ev.v_ext;
         uint32_t noff;
         SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = (uint32_t)P.arena;
@@ -1397,6 +1416,216 @@ __global__ __launch_bounds__(64) void expand_backup_select_kernel(Params P, cons
     expand_backup_core(P, lds, blockIdx.x, p, v);
     __syncthreads();                                   // the slot record, the pool and the hand-off record: stores before loads
     select_core(P, lds, blockIdx.x, planes);
+}
+
+// ---- free-running stepped path (ccsp_advance): every slot at its own simulation of its own ply ---------------------------------
+// One call = for every slot: take the answer (p, v) to the request it left last time (a leaf to expand, or a ply's root), then
+// go on -- finish the ply when its simulations are done (pi, move, rules, log row), play opening plies, start the next ply, select --
+// until the slot needs the evaluator again: planes out, request recorded, return.  What the lock-step kernels above do in five
+// launches per ply and `sims` launches in between, with every slot waiting for the slowest, a slot does here at its own pace:
+//   * a simulation that ends in a won leaf (MCTS.py:81-90) needs no evaluator: it is backed up and the next one starts at once;
+//   * TREE REUSE: selfplay.make_move hands the chosen child back as a FRESH root (selfplay.py:130-133) and the next ply evaluates the
+//     positions of its subtree all over again.  The evaluator is a function of the position alone (tests/test_model.py), so the
+//     previous ply's tree (kept in the other pool) already holds the answer for every position the new search reaches inside the
+//     played move's subtree: a block records the offset of the SAME position's block in the previous tree ("shadow", found through
+//     its parent's: same path = same position, last two moves included), and a leaf whose shadow exists is expanded from that
+//     block's P[K] and v -- the bits the net would return -- without leaving the kernel.  Trees, pi and games are unchanged
+//     (tests: the free-running run against one lock-step slot per game); only the number of evaluator launches per ply falls.
+// Two kernels per call, because what happens once per ply (Dirichlet noise, pi, sampling, the end-of-ply rules, opening plies: 80-130
+// vector registers) must not set the register budget of what happens every simulation: the per-simulation kernel has to fit beside
+// the evaluator's two waves per SIMD (352 of 512 registers).
+//   boundary_kernel   slots at a ply boundary only (the others leave after reading 12 bytes): root expansion from the evaluator's answer,
+//                     or: the finished ply's pi / move / rules / log row, opening plies of a new game, the next ply's root -- from the
+//                     previous tree (reuse), else its planes go out as a request
+//   advance_kernel    slots in a search: expansion + backup of the answered leaf, then selection -- and on through won leaves and
+//                     reused positions -- until a leaf needs the evaluator (planes out) or the ply's simulations are done
+// Slot word 15: bits 0-7 phase (0 = at a ply boundary, 1 = searching, 2 = simulations done), bit 8 = which pool holds the current tree,
+// bits 32-63 = offset / 8, in the OTHER pool, of the block of the current ply's root position (0 = none).  Pending.kind: 0 no request,
+// 1 a leaf, 3 the root.
+// `budget`: simulations a slot may complete without the evaluator (won leaves, reused positions) in one launch; with the budget
+// spent a slot selects once more and leaves its request if that leaf needs the evaluator -- otherwise it returns without one (its row
+// of the next evaluator launch is idle) and selects the same leaf again in the next call.  Bounds the launch's length.
+__device__ __forceinline__ void write_w15(const Params &P, int g, uint32_t phase, uint32_t half, uint32_t root_shadow) {
+    if (lane_id() == 0) P.slots[g].w[15] = (uint64_t)phase | ((uint64_t)half << 8) | ((uint64_t)root_shadow << 32);
+}
+
+__global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags) {
+    __shared__ Lds lds;
+    const int g = blockIdx.x, lane = lane_id();
+    const uint64_t w15 = uni64(P.slots[g].w[15]);
+    uint32_t phase = (uint32_t)(w15 & 0xFF), half = (uint32_t)((w15 >> 8) & 1), root_shadow = (uint32_t)(w15 >> 32);
+    const uint32_t kind = uni32(P.pend[g].kind);
+    if (phase == 1) return;                               // in a search: advance_kernel's business
+    Slot sl = load_slot(P.slots + g);
+    if (sl.status != CCSP_ST_RUNNING) return;
+    __builtin_amdgcn_s_setprio(2);
+    ccsp_load_lines_to_lds(&lds.T, lane, 64);
+    __syncthreads();
+    const bool reuse = (flags & CCSP_ADVANCE_REUSE) != 0;
+    uint32_t *acc = P.stepacc + (size_t)g * 8;
+    Tally tl; tally_zero(tl);
+    bool expand_root = false;
+    EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = 0.0f; ev.p_edges = nullptr; ev.shadow = 0;
+    uint32_t hit = 0, request = 0;
+    if (kind == 3) {                                      // the evaluator's answer for this ply's root (root_expand_kernel)
+        ev.v_ext = v[g];
+        expand_root = true;
+    } else {
+        if (phase == 2) {                                 // the ply's search is done: pi, move, rules, log row (ply_end_kernel)
+            // the sample log is shared by the slots and emptied by the host every few plies: a slot that could find it full waits
+            // a call rather than lose its row (a game with a missing row ends in ERROR)
+            if ((flags & CCSP_ADVANCE_LOG_GUARD) &&
+                *reinterpret_cast<volatile unsigned long long *>(P.log_count) + (unsigned long long)P.n_slots > P.log_cap) return;
+            uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
+            const uint64_t game0 = sl.game;
+            uint32_t cw = 0;
+            wave_finish_ply(P, lds, sl, pool, tl, &cw);
+            fast_forward_opening(P, lds, sl, game0, tl);
+            // the ply's tallies -> global counters
+            tl.expansions += acc[0]; tl.terminal_sims += acc[1]; tl.sims += acc[2]; tl.sum_depth += acc[3];
+            tl.sum_children += acc[4]; tl.select_edges += acc[5];
+            if (lane == 0 && acc[6]) atomicAdd(&P.counters[CCSP_CNT_CACHE_HITS], (unsigned long long)acc[6]);
+            __syncthreads();
+            if (lane < 8) acc[lane] = 0u;
+            __syncthreads();
+            root_shadow = (reuse && sl.status == CCSP_ST_RUNNING && sl.game == game0 && cw != CHILD_LEAF && cw != CHILD_TERMINAL) ? (cw >> 7) : 0u;
+            if (reuse) half ^= 1u;                        // the tree just searched stays where it is; the next ply grows in the other pool
+            phase = 0;
+        }
+        while (sl.status == CCSP_ST_RUNNING && sl.opening_left > 0) { wave_opening_ply(P, lds, sl, tl); root_shadow = 0; }   // selfplay.py:32-33
+        if (sl.status == CCSP_ST_RUNNING) {
+            if (reuse && root_shadow != 0) {              // the root was a node of the previous ply's tree: its priors and value are there
+                const uint8_t *ob = (half ? P.pool : P.pool2) + (uint64_t)g * P.pool_stride + ((uint64_t)root_shadow << 3);
+                ev.kind = CCSP_EVAL_CACHED; ev.p_edges = reinterpret_cast<const double *>(ob + BLOCK_HDR);
+                ev.v_ext = reinterpret_cast<const float *>(ob + 32)[3]; ev.shadow = root_shadow;
+                expand_root = true; hit = 1;
+            } else {
+                wave_encode(lds, sl.st, (int)sl.player, planes + (uint64_t)g * CCSP_PLANES);
+                request = 3;
+            }
+        }
+    }
+    if (expand_root) {                                    // selfplay.py:117-124: expansion + Dirichlet noise
+        uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
+        SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = 0; cx.player = sl.player; cx.pool_used = 0; cx.nsum_bias = 0;
+        uint32_t off;
+        const int K = wave_expand(lds, cx, pool, sl.st, (int)sl.player, ev, 0, true, off);
+        sl.root_k = (uint32_t)K; sl.pool_used = cx.pool_used; sl.sim = 0; sl.expansions += 1;
+        if (K == 0) { sl.status = CCSP_ST_ERROR; tl.errors += 1; }             // assert, selfplay.py:118
+        if (lane == 0) { acc[0] += 1u; acc[4] += (uint32_t)K; acc[6] += hit; }
+        phase = 1;
+    }
+    if (lane == 0) {
+        P.pend[g].kind = request;
+        if (request && model_sel) model_sel[g] = (uint8_t)(sl.player == 2 ? 1 : 0);    // whose model answers (selfplay.py:30,36,59)
+    }
+    write_w15(P, g, phase, half, root_shadow);
+    store_slot(P.slots + g, sl);
+    tally_flush(P, tl);
+}
+
+__global__ __launch_bounds__(64) void advance_kernel(Params P, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, int budget) {
+    __shared__ Lds lds;
+    const int g = blockIdx.x, lane = lane_id();
+    const uint64_t w15 = uni64(P.slots[g].w[15]);
+    uint32_t phase = (uint32_t)(w15 & 0xFF);
+    const uint32_t half = (uint32_t)((w15 >> 8) & 1), root_shadow = (uint32_t)(w15 >> 32);
+    if (phase != 1) return;                               // at a ply boundary: boundary_kernel's business
+    Slot sl = load_slot(P.slots + g);
+    if (sl.status != CCSP_ST_RUNNING) return;
+    __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch: the short tree kernels go first
+    ccsp_load_lines_to_lds(&lds.T, lane, 64);
+    __syncthreads();
+    const bool reuse = (flags & CCSP_ADVANCE_REUSE) != 0;
+    uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
+    const uint8_t *old = (half ? P.pool : P.pool2) + (uint64_t)g * P.pool_stride;
+    uint64_t *path = P.path + (uint64_t)g * P.path_stride;
+    uint32_t a_exp = 0, a_term = 0, a_sims = 0, a_depth = 0, a_children = 0, a_edges = 0, a_hits = 0, errors = 0;
+    Pending pd;
+    {
+        const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(P.pend + g);
+        const ulonglong2 a = q[0], b = q[1], c = q[2];
+        pd.leaf.occ0 = uni64(a.x); pd.leaf.occ1 = uni64(a.y); pd.leaf.a = uni64(b.x); pd.leaf.b = uni64(b.y);
+        const uint64_t c0 = uni64(c.x), c1 = uni64(c.y);
+        pd.kind = (uint32_t)c0; pd.depth = (uint32_t)(c0 >> 32); pd.link_off = (uint32_t)c1; pd.leaf_player = (uint32_t)(c1 >> 32);
+    }
+    bool answered = pd.kind == 1;                         // the evaluator's answer for the leaf this slot asked about last time
+    uint32_t request = 0;
+    int spent = 0;
+    for (;;) {
+        ccsp_sr leaf; int leaf_player, depth; uint32_t link_off;
+        uint64_t mypath = 0; double myW = 0.0; uint32_t myN = 0;
+        bool terminal = false, have_stats = false;
+        EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = 0.0f; ev.p_edges = nullptr; ev.shadow = 0;
+        if (answered) {                                   // expansion with (p, v) + backup (expand_backup_core)
+            answered = false;
+            leaf = pd.leaf; leaf_player = (int)pd.leaf_player; depth = (int)pd.depth; link_off = pd.link_off;
+            ev.v_ext = v[g];
+            mypath = (lane < depth) ? path[lane] : 0;
+        } else {
+            if (sl.sim >= (uint32_t)P.sims) { phase = 2; break; }      // the search is done: boundary_kernel ends the ply in the next call
+            const bool last = spent >= budget;            // budget spent: one more selection, taken up only if it asks the evaluator
+            SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
+            uint32_t edges = 0;
+            const Leaf lf = reuse ? wave_select<false, false, true>(P.sqrt_tab, nullptr, cx, pool, path, sl.sim, mypath, myW, myN, edges)
+                                  : wave_select<false, false, false>(P.sqrt_tab, nullptr, cx, pool, path, sl.sim, mypath, myW, myN, edges);
+            a_sims += 1; a_depth += (uint32_t)lf.depth; a_edges += edges;
+            leaf = lf.st; leaf_player = lf.player; depth = lf.depth; link_off = lf.link_off;
+            have_stats = true;
+            if (lf.kind == 2) {                           // a won leaf: backed up at once (MCTS.py:81-90)
+                if (last) { a_sims -= 1; a_depth -= (uint32_t)lf.depth; a_edges -= edges; break; }   // (selected again in the next call)
+                terminal = true; a_term += 1;
+            } else {
+                uint32_t shadow = 0;
+                if (reuse && lf.parent_shadow != 0) {     // the leaf's position in the previous ply's tree, through its parent's block there
+                    const uint8_t *opb = old + ((uint64_t)lf.parent_shadow << 3);
+                    const uint32_t cw = uni32(*reinterpret_cast<const uint32_t *>(opb + BLOCK_HDR + 20 * lf.parent_k + 4 * lf.sel));
+                    if (cw != CHILD_LEAF && cw != CHILD_TERMINAL) shadow = cw >> 7;
+                }
+                if (shadow == 0) {                        // the evaluator is needed: leaf planes out, the hand-off record for the next call
+                    if (lane == 0) {
+                        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(P.pend + g);
+                        q[0] = make_ulonglong2(leaf.occ0, leaf.occ1);
+                        q[1] = make_ulonglong2(leaf.a, leaf.b);
+                        q[2] = make_ulonglong2(1ULL | ((uint64_t)(uint32_t)depth << 32), (uint64_t)link_off | ((uint64_t)(uint32_t)leaf_player << 32));
+                    }
+                    wave_encode(lds, leaf, leaf_player, planes + (uint64_t)g * CCSP_PLANES);
+                    request = 1;
+                    break;
+                }
+                if (last) { a_sims -= 1; a_depth -= (uint32_t)lf.depth; a_edges -= edges; break; }   // (no request: this slot's row of the next evaluator launch is idle)
+                const uint8_t *ob = old + ((uint64_t)shadow << 3);      // expanded there: the evaluator's answer is in that block
+                ev.kind = CCSP_EVAL_CACHED; ev.p_edges = reinterpret_cast<const double *>(ob + BLOCK_HDR);
+                ev.v_ext = reinterpret_cast<const float *>(ob + 32)[3]; ev.shadow = shadow;
+                a_hits += 1;
+            }
+            spent += 1;
+        }
+        if (!terminal) {
+            SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
+            uint32_t noff;
+            const int k = wave_expand(lds, cx, pool, leaf, leaf_player, ev, 0, false, noff);
+            sl.pool_used = cx.pool_used;
+            if (ev.kind == CCSP_EVAL_CACHED && k != (int)reinterpret_cast<const uint32_t *>(old + ((uint64_t)ev.shadow << 3) + 32)[0]) {
+                sl.status = CCSP_ST_ERROR; errors += 1; break;            // (cannot happen: the same position has the same moves)
+            }
+            if (k > 0 && lane == 0) *reinterpret_cast<uint32_t *>(pool + link_off) = ((noff >> 3) << 7) | (uint32_t)k;
+            a_exp += 1; a_children += (uint32_t)k; sl.expansions += 1;
+            __syncthreads();
+        }
+        wave_backup(pool, path, mypath, myW, myN, have_stats, depth, terminal, ev.v_ext);
+        sl.sim += 1;
+        __syncthreads();                                  // this simulation's stores before the next one's loads
+    }
+    if (lane == 0) {
+        if (request != 1) P.pend[g].kind = 0;             // nothing asked: the search is done, or the budget is spent
+        if (request && model_sel) model_sel[g] = (uint8_t)(sl.player == 2 ? 1 : 0);    // whose model answers (selfplay.py:30,36,59)
+        uint32_t *acc = P.stepacc + (size_t)g * 8;
+        acc[0] += a_exp; acc[1] += a_term; acc[2] += a_sims; acc[3] += a_depth; acc[4] += a_children; acc[5] += a_edges; acc[6] += a_hits;
+        if (errors) atomicAdd(&P.counters[CCSP_CNT_ERRORS], (unsigned long long)errors);
+    }
+    write_w15(P, g, phase, half, root_shadow);
+    store_slot(P.slots + g, sl);
 }
 
 // stepped path, phase 5: pi, sampling, move, rules (or the random opening move)
@@ -1511,7 +1740,7 @@ int ccsp_destroy(ccsp_ctx *ctx) {
     if (!ctx) return CCSP_OK;
     ctx_scope scope_(ctx, nullptr);
     Params &P = ctx->P;
-    void *ptrs[] = {P.slots, P.pend, P.pool, P.path, ctx->sqrt_tab, ctx->pow_tab, ctx->rcp_tab, P.counters, P.stepacc, P.visit_hist,
+    void *ptrs[] = {P.slots, P.pend, P.pool, P.pool2, P.path, ctx->sqrt_tab, ctx->pow_tab, ctx->rcp_tab, P.counters, P.stepacc, P.visit_hist,
                     P.log_state, P.log_meta, P.log_pi, P.log_count, P.results};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete ctx;
@@ -1733,6 +1962,33 @@ int ccsp_ply_end(ccsp_ctx *ctx, void *stream) {
     return CCSP_OK;
 }
 
+// ---- free-running stepped path ------------------------------------------------------------------------------------------
+
+int ccsp_enable_tree_reuse(ccsp_ctx *ctx) {
+    if (!ctx) return CCSP_EINVAL;
+    if (ctx->P.pool2) return CCSP_OK;
+    CTX_ENTER(ctx, nullptr);
+    const int rc = ccsp_alloc_status(hipMalloc((void **)&ctx->P.pool2, ctx->pool_bytes), "hipMalloc(pool2)");
+    if (rc != CCSP_OK) { ctx->P.pool2 = nullptr; return rc; }
+    return CCSP_OK;
+}
+
+static int g_advance_budget = 4;
+int ccsp_debug_advance_budget(int n) { const int was = g_advance_budget; if (n >= 0) g_advance_budget = n; return was; }
+
+int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream) {
+    if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD))) return CCSP_EINVAL;
+    if (ctx->cfg.mode != CCSP_MODE_SELFPLAY) return CCSP_EINVAL;          // Game.start's seats are served by the lock-step kernels
+    if ((flags & CCSP_ADVANCE_REUSE) && !ctx->P.pool2) return CCSP_ESTATE;  // ccsp_enable_tree_reuse first (an allocation: not inside a captured graph)
+    if (ctx->phase != 0) return CCSP_ESTATE;                                // not in the middle of a lock-step ply
+    CTX_ENTER(ctx, stream);
+    hipLaunchKernelGGL(boundary_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags);
+    hipLaunchKernelGGL(advance_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget);
+    CCSP_HIPCHK(hipGetLastError());
+    ctx->opening_plies = -1;
+    return CCSP_OK;
+}
+
 // ---- read-back (synchronous; host buffers) ---------------------------------------------------------------
 
 int ccsp_read_counters(ccsp_ctx *ctx, uint64_t *out /* [CCSP_CNT_COUNT] */) {
@@ -1743,10 +1999,10 @@ int ccsp_read_counters(ccsp_ctx *ctx, uint64_t *out /* [CCSP_CNT_COUNT] */) {
     // plus what the stepped kernels have tallied per slot since the last ply_end
     std::vector<uint32_t> acc((size_t)ctx->P.n_slots * 8);
     CCSP_HIPCHK(hipMemcpy(acc.data(), ctx->P.stepacc, acc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    static const int map[6] = {CCSP_CNT_EXPANSIONS, CCSP_CNT_TERMINAL_SIMS, CCSP_CNT_SIMS, CCSP_CNT_SUM_DEPTH, CCSP_CNT_SUM_CHILDREN,
-                               CCSP_CNT_SELECT_EDGES};
+    static const int map[7] = {CCSP_CNT_EXPANSIONS, CCSP_CNT_TERMINAL_SIMS, CCSP_CNT_SIMS, CCSP_CNT_SUM_DEPTH, CCSP_CNT_SUM_CHILDREN,
+                               CCSP_CNT_SELECT_EDGES, CCSP_CNT_CACHE_HITS};
     for (int g = 0; g < ctx->P.n_slots; g++)
-        for (int i = 0; i < 6; i++) out[map[i]] += acc[(size_t)g * 8 + i];
+        for (int i = 0; i < 7; i++) out[map[i]] += acc[(size_t)g * 8 + i];
     return CCSP_OK;
 }
 
@@ -1824,13 +2080,27 @@ int ccsp_read_results(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_game_resul
     return CCSP_OK;
 }
 
+// device address of the tree a slot searched last: the first pool, or -- on the free-running path with tree reuse, where consecutive
+// plies alternate between two pools (slot word 15) -- the pool of the search in progress / of the ply just finished
+static int tree_of_slot(ccsp_ctx *ctx, int slot, const uint8_t **out) {
+    uint64_t w15 = 0;
+    CCSP_HIPCHK(hipMemcpy(&w15, &ctx->P.slots[slot].w[15], sizeof w15, hipMemcpyDeviceToHost));
+    uint32_t half = (uint32_t)((w15 >> 8) & 1);
+    if (ctx->P.pool2 && (w15 & 0xFF) == 0) half ^= 1u;                      // at a ply boundary: the finished ply's tree is in the other pool
+    if (!ctx->P.pool2) half = 0;
+    *out = (half ? ctx->P.pool2 : ctx->P.pool) + (uint64_t)slot * ctx->P.pool_stride;
+    return CCSP_OK;
+}
+
 // root edges of a slot's current tree (valid after a ply was searched, until the next one starts)
 int ccsp_read_root(ccsp_ctx *ctx, int slot, int *k_out, uint32_t *N, double *W, double *Pr, uint16_t *mv) {
     if (!ctx || slot < 0 || slot >= ctx->P.n_slots || !k_out) return CCSP_EINVAL;
     CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
     std::vector<uint8_t> blk(MAX_BLOCK_BYTES);
-    CCSP_HIPCHK(hipMemcpy(blk.data(), ctx->P.pool + (uint64_t)slot * ctx->P.pool_stride, MAX_BLOCK_BYTES, hipMemcpyDeviceToHost));
+    const uint8_t *tree = nullptr;
+    { const int rc = tree_of_slot(ctx, slot, &tree); if (rc != CCSP_OK) return rc; }
+    CCSP_HIPCHK(hipMemcpy(blk.data(), tree, MAX_BLOCK_BYTES, hipMemcpyDeviceToHost));
     const int K = (int)*reinterpret_cast<uint32_t *>(blk.data() + 32);
     if (K <= 0 || K > CCSP_MAX_MOVES) return CCSP_ESTATE;
     *k_out = K;
@@ -1867,7 +2137,9 @@ int ccsp_debug_tree_digest(ccsp_ctx *ctx, int slot, uint64_t *digest, uint64_t *
     CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
     std::vector<uint8_t> pool(ctx->P.pool_stride);
-    CCSP_HIPCHK(hipMemcpy(pool.data(), ctx->P.pool + (uint64_t)slot * ctx->P.pool_stride, ctx->P.pool_stride, hipMemcpyDeviceToHost));
+    const uint8_t *tree = nullptr;
+    { const int rc = tree_of_slot(ctx, slot, &tree); if (rc != CCSP_OK) return rc; }
+    CCSP_HIPCHK(hipMemcpy(pool.data(), tree, ctx->P.pool_stride, hipMemcpyDeviceToHost));
     *digest = 0; *nodes = 0; *edges = 0;
     digest_block(pool.data(), 0, *digest, *nodes, *edges);
     return CCSP_OK;

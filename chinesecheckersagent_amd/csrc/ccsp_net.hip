@@ -46,12 +46,15 @@ constexpr int NPOL = 294, NPOL_PAD = 304;
 #endif
 // k-segments (accumulation chains) every output of a layer kind is summed from, ((c0 + c1) + c2) + ... in fixed order -- the same in
 // every workgroup shape.  A float32 FMA chain over K terms drifts like sqrt(K) roundings; cutting it into segments of 16-48 k costs
-// NSEG - 1 vector adds per output and no MFMA (tools/n1_floor.py prices the orders).
+// NSEG - 1 vector adds per output and no MFMA.  MEASURED in round 4 on 4096 self-play positions x 3 weight files (3.6 M logits,
+// profiles/r4_n1_wide_variants.json): two segments in the stem and the first 1x1 take the logits further than 1e-5 from the float64
+// restatement from 215 to 82 and the mean distance down by a tenth, but NOT the maximum (2.0e-5 -> 2.2e-5; it wanders between 1.8e-5
+// and 2.7e-5 over six segmentations) -- and the adds take the fp32 lanes the MFMA shares: +0.8 % kernel time.  Not adopted: all 1.
 #ifndef CCSP_NET_SEG_STEM
-#define CCSP_NET_SEG_STEM 2              // stem 3x3, K = 80 (5 k-blocks: 2 + 3)
+#define CCSP_NET_SEG_STEM 1              // stem 3x3, K = 80 (5 k-blocks)
 #endif
 #ifndef CCSP_NET_SEG_L1
-#define CCSP_NET_SEG_L1 2                // blocks' first 1x1, K = 64 (4 k-blocks: 2 + 2)
+#define CCSP_NET_SEG_L1 1                // blocks' first 1x1, K = 64 (4 k-blocks)
 #endif
 #ifndef CCSP_NET_SEG_L2
 #define CCSP_NET_SEG_L2 4                // blocks' 3x3, K = 288 (18 k-blocks); a multiple of the waves sharing the last row tile (4)

@@ -93,6 +93,18 @@ class SelfPlayEngine(object):
     def ply_end(self, stream=None):
         check(self.L.ccsp_ply_end(self.ctx, _stream_ptr(stream)), 'ccsp_ply_end')
 
+    # free-running stepped path
+    def enable_tree_reuse(self):
+        """the second tree pool ccsp_advance(reuse=True) needs (an allocation: call it before capturing a graph)"""
+        check(self.L.ccsp_enable_tree_reuse(self.ctx), 'ccsp_enable_tree_reuse')
+
+    def advance(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stream=None):
+        """every slot: take the answer (p, v) to its last request, go on to its next one (planes out)"""
+        self._check_pv(p, v)
+        flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0)
+        check(self.L.ccsp_advance(self.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(),
+                                  model_sel.data_ptr() if model_sel is not None else None, flags, _stream_ptr(stream)), 'ccsp_advance')
+
     def _check_pv(self, p, v):
         import torch
         assert p.is_cuda and p.dtype == torch.float64 and p.is_contiguous() and p.numel() == self.n_slots * NUM_ACTIONS
@@ -102,7 +114,9 @@ class SelfPlayEngine(object):
     def counters(self):
         out = np.zeros(CNT_COUNT, dtype=np.uint64)
         check(self.L.ccsp_read_counters(self.ctx, out.ctypes.data), 'ccsp_read_counters')
-        return {name: int(out[i]) for i, name in enumerate(CNT_NAMES)}
+        d = {name: int(out[i]) for i, name in enumerate(CNT_NAMES)}
+        d['cache_hits'] = int(out[_lib.CNT_CACHE_HITS])
+        return d
 
     def visit_histogram(self):
         out = np.zeros(NUM_ACTIONS, dtype=np.uint64)

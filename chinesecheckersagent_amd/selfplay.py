@@ -65,10 +65,20 @@ def _warn(msg):
 
 
 class BatchSelfPlay(object):
-    """n_slots concurrent games through the stepped path (external evaluator)."""
+    """n_slots concurrent games through the stepped path (external evaluator).
+
+    Two ways of stepping them (same games, bit for bit):
+      lock-step (default)   every slot plays the same ply's same simulation: per ply ply_begin -> net -> root_expand -> sims x
+                            [net -> expand_backup_select] -> ply_end; the form the reference-made tree fixtures are replayed in
+      free_running=True     ccsp_advance: every slot at its own simulation of its own ply -- [net -> advance] for ever; simulations that
+                            end in a won leaf never wait for the net, and with `reuse` (default when there is ONE model) positions the
+                            previous ply's tree already holds below the move that was played are expanded from that tree instead of
+                            asking the net again (selfplay.py:130-133 discards it).  play_ply() is then sims + 1 such steps: a ply's
+                            worth of evaluator launches, in which a slot plays 1.3-1.5 plies.  The delivered mode (SelfPlayRun)."""
 
     def __init__(self, model1, model2=None, n_slots=1, sims=MCTS_SIMULATIONS, seed=None, first_game=0, game_stride=1,
-                 max_games=None, randomised=False, auto_restart=False, device=0, log_capacity=None, use_graph=True):
+                 max_games=None, randomised=False, auto_restart=False, device=0, log_capacity=None, use_graph=True,
+                 free_running=False, reuse=None, log_guard=False):
         import torch
         self.torch = torch
         self.m1 = _batched(model1)
@@ -85,6 +95,19 @@ class BatchSelfPlay(object):
         self.use_graph = bool(use_graph) and hasattr(self.m1, 'model') and (self.m2 is None or hasattr(self.m2, 'model'))
         self._graph = None
         self._root_is_p2 = torch.zeros(n_slots, dtype=torch.bool, device=dev)
+        self.free_running = bool(free_running)
+        self.reuse = self.free_running and (self.m2 is None if reuse is None else bool(reuse))
+        if self.reuse and self.m2 is not None:
+            raise ValueError('tree reuse needs ONE model: the previous ply of a two-model game was searched with the other one (selfplay.py:30,59)')
+        self.log_guard = bool(log_guard)
+        self.steps = 0                                     # free-running: [net -> advance] steps taken
+        if self.free_running:
+            if self.reuse:
+                self.eng.enable_tree_reuse()
+            self._model_sel = torch.zeros(n_slots, dtype=torch.uint8, device=dev) if self.m2 is not None else None
+            self._p0 = torch.zeros((n_slots, NUM_ACTIONS), dtype=torch.float64, device=dev)     # the first call's answer to no request
+            self._v0 = torch.zeros(n_slots, dtype=torch.float32, device=dev)
+            self._started = False
 
     def _evaluate(self, root_is_p2):
         p, v = self.m1.evaluate_batch(self.planes)
@@ -133,9 +156,69 @@ class BatchSelfPlay(object):
                 raise
             _warn('hipGraph capture of the simulation steps failed (%r): this batch runs on plain launches' % (ex,))
 
+    # ---- free-running stepping ---------------------------------------------------------------------------------------------
+    def _evaluate_free(self):
+        p, v = self.m1.evaluate_batch(self.planes)
+        if self.m2 is not None:                            # the request names the model: player two's searches ask model2 (selfplay.py:30,36,59)
+            p2, v2 = self.m2.evaluate_batch(self.planes)
+            sel = self._model_sel.bool()
+            p = self.torch.where(sel[:, None], p2, p)
+            v = self.torch.where(sel, v2, v)
+        return p.contiguous(), v.contiguous()
+
+    def _advance(self, p, v):
+        self.eng.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
+
+    def _capture_free(self):
+        torch = self.torch
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                     # warm-up on a side stream (allocator)
+                for _ in range(2):
+                    self._evaluate_free()
+            torch.cuda.current_stream().wait_stream(s)
+            self._unroll = 25
+            keep = []
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):                      # capture only: nothing executes here
+                for _ in range(self._unroll):
+                    gp, gv = self._evaluate_free()
+                    self._advance(gp, gv)
+                    keep.append((gp, gv))
+            self._graph, self._graph_out = g, keep
+        except Exception as ex:
+            self.use_graph = False
+            self._graph = None
+            if _strict():
+                raise
+            _warn('hipGraph capture of the free-running steps failed (%r): this batch runs on plain launches' % (ex,))
+
+    def play_steps(self, n):
+        """n steps of [one batched forward of the net -> ccsp_advance]"""
+        assert self.free_running
+        if not self._started:
+            self._advance(self._p0, self._v0)              # nothing is pending yet: every slot starts its game and leaves its first request
+            self._started = True
+        if self.use_graph and self._graph is None:
+            self._capture_free()
+        done = 0
+        if self._graph is not None:
+            while n - done >= self._unroll:
+                self._graph.replay()
+                done += self._unroll
+        while done < n:
+            p, v = self._evaluate_free()
+            self._advance(p, v)
+            done += 1
+        self.steps += n
+
     def play_ply(self):
         """one ply of every running slot: random opening move, or root expansion + sims x
-        (select -> net -> expand/backup) + pi + move"""
+        (select -> net -> expand/backup) + pi + move.  free_running: sims + 1 steps of [net -> advance] instead -- the same number of
+        evaluator launches, in which every slot gets as far as it gets"""
+        if self.free_running:
+            return self.play_steps(self.sims + 1)
         e = self.eng
         e.ply_begin(self.planes)
         self._root_is_p2.copy_(self.planes[:, 0, 0, 6] == 1)
@@ -429,7 +512,7 @@ class SelfPlayRun(object):
 
     def __init__(self, model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False, first_game=0,
                  game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY, use_graph=True, keep_records=True,
-                 sink=None, n_parts=None):
+                 sink=None, n_parts=None, free_running=True, reuse=None):
         n_games = int(n_games)
         n_slots = max(1, min(n_games, int(max_slots)))
         if n_parts is None:
@@ -439,6 +522,12 @@ class SelfPlayRun(object):
         kw = dict(sims=sims, seed=seed, first_game=first_game, game_stride=game_stride, max_games=n_games, randomised=randomised,
                   auto_restart=True, device=device, use_graph=use_graph)
         cap = n_slots * (self.harvest_every + 1)
+        if free_running and hasattr(_batched(model1), 'model'):
+            # slots run at their own pace (BatchSelfPlay): between two harvests a slot plays up to ~1.5 plies per `play_ply`; a slot that
+            # could find the log full waits for the harvest (log_guard) instead of losing a row
+            kw.update(free_running=True, reuse=reuse, log_guard=True)
+            cap = n_slots * (2 * self.harvest_every + 2)
+        self.free_running = bool(kw.get('free_running'))
         if n_parts > 1:
             self.b = PipelinedSelfPlay(model1, model2, n_slots=n_slots, n_parts=n_parts, log_capacity=cap, **kw)
             self.counters = self.b.counters

@@ -197,6 +197,8 @@ enum {
     CCSP_CNT_SELECT_EDGES,    /* sum over selection levels of the edges scanned (for the byte model) */
     CCSP_CNT_SAMPLES,         /* rows appended to the sample log */
     CCSP_CNT_ERRORS,
+    CCSP_CNT_CACHE_HITS = 15, /* expansions answered from the previous ply's tree instead of the evaluator (ccsp_advance with CCSP_ADVANCE_REUSE);
+                                 they are expansions all the same: CCSP_CNT_EXPANSIONS counts them too */
     CCSP_CNT_COUNT = 16
 };
 
@@ -240,6 +242,29 @@ int ccsp_expand_backup(ccsp_ctx *ctx, const double *p, const float *v, void *str
  * [evaluate -> expand_backup -> select]); same results */
 int ccsp_expand_backup_select(ccsp_ctx *ctx, const double *p, const float *v, float *planes, void *stream);
 int ccsp_ply_end(ccsp_ctx *ctx, void *stream);
+
+/* Free-running stepped path (self-play mode): the same search, every slot at its own simulation of its own ply.  One call =
+ * for every slot: take the answer (p[slot], v[slot]) to the request the slot left in the previous call (a leaf to expand,
+ * MCTS.py:93-118, or a ply's root, selfplay.py:117-124), then go on -- end the ply when its `sims` simulations are done (MCTS.py:127-153,
+ * selfplay.py:38-74), play opening plies (selfplay.py:83-104), start the next ply, select (MCTS.py:49-76) -- until the slot needs the
+ * evaluator again: planes[slot] out, request recorded.  The caller's loop is [evaluate planes -> ccsp_advance] for ever; the first call
+ * finds no request and only emits.  Simulations that end in a won leaf (MCTS.py:81-90) never wait for the evaluator.
+ *   CCSP_ADVANCE_REUSE      selfplay.make_move returns the chosen child as a fresh root (selfplay.py:130-133) and the next ply evaluates the
+ *                           positions of its subtree again; with this flag a position the previous ply's tree holds below the move that was
+ *                           played is expanded from that tree's priors and value -- the evaluator is a function of the position alone, so
+ *                           trees, pi and games are bit-identical, only the evaluator is asked less often (CCSP_CNT_CACHE_HITS).  Needs
+ *                           ccsp_enable_tree_reuse (a second tree pool).  NOT for two-model games: the previous ply was searched with the
+ *                           other player's model (selfplay.py:30,59).
+ *   CCSP_ADVANCE_LOG_GUARD  a slot whose finished ply might not find a free row in the sample log waits for the caller's next
+ *                           ccsp_log_clear instead of ending its game in CCSP_ST_ERROR (for callers that harvest the log as they go).
+ * model_sel (device, [n_slots], may be NULL): 1 where the request is to be answered by player two's model (selfplay.py:30,36,59).
+ * Slots that ask for nothing in a call (game over, budget of evaluator-free simulations spent) ignore their row of the next answer. */
+enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2 };
+int ccsp_enable_tree_reuse(ccsp_ctx *ctx);
+int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
+/* evaluator-free simulations (won leaves, reused positions) a slot may complete in ONE ccsp_advance (default 4: bounds the launch's
+ * length; results do not depend on it).  Returns the previous value; n < 0 only reads it. */
+int ccsp_debug_advance_budget(int n);
 
 /* ---- evaluator: the policy/value network as one fused kernel (row N1; Model.predict, model.py:21-24) ---- */
 

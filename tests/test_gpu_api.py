@@ -388,6 +388,54 @@ def test_randomised_two_model_games_at_1024_restarting_slots(golden_dir):
         assert a == w, 'game %d differs' % (first + k)
 
 
+def test_free_running_slots_play_the_lock_step_games(golden_dir):
+    """ccsp_advance (BatchSelfPlay(free_running=True): every slot at its own simulation of its own ply, won leaves backed up without the
+    net, positions of the previous ply's tree reused instead of evaluated again) plays EXACTLY the games of the lock-step kernels: status,
+    reward, every searched position and pi of 24 games; the same number of expansions, terminal simulations and simulations; whatever the
+    budget of evaluator-free simulations per call; with and without tree reuse; on plain launches and on captured graphs; two-model
+    games (no reuse: the previous ply was searched with the other model)"""
+    from chinesecheckersagent_amd import _lib, selfplay as sp
+    from chinesecheckersagent_amd.model import ResidualCNN
+    L = _lib.lib()
+    m = ResidualCNN()
+    m.load_weights(golden_dir + '/good_model.h5')
+    n, sims, seed, first = 24, 16, 41, 900
+    b = sp.BatchSelfPlay(m, n_slots=n, sims=sims, seed=seed, first_game=first, max_games=n, log_capacity=n * 600)
+    want = _records(b.run_to_completion(max_plies=1100))
+    cw = b.eng.counters()
+    b.close()
+    assert any(h is None for h, _ in want) and sum(isinstance(h, list) for h, _ in want) > n // 2 and cw['cache_hits'] == 0
+    was = L.ccsp_debug_advance_budget(-1)
+    try:
+        for budget, reuse, graph in ((4, True, True), (0, True, True), (1, True, False), (64, True, True), (4, False, True)):
+            L.ccsp_debug_advance_budget(budget)
+            b = sp.BatchSelfPlay(m, n_slots=n, sims=sims, seed=seed, first_game=first, max_games=n, log_capacity=n * 600,
+                                 free_running=True, reuse=reuse, use_graph=graph)
+            got = _records(b.run_to_completion(max_plies=1100))
+            c = b.eng.counters()
+            b.close()
+            assert got == want, (budget, reuse, graph)
+            for k in ('expansions', 'terminal_sims', 'sims', 'plies', 'mcts_plies', 'games_won', 'games_discarded', 'sum_depth', 'sum_children',
+                      'select_edges', 'samples', 'errors'):
+                assert c[k] == cw[k], (k, budget, reuse, graph)
+            assert (c['cache_hits'] > 0.1 * c['expansions']) if reuse else c['cache_hits'] == 0, (c['cache_hits'], c['expansions'])
+    finally:
+        L.ccsp_debug_advance_budget(was)
+    # two models, randomised starts
+    m2 = ResidualCNN()
+    m2.load_weights(golden_dir + '/good_model2.h5')
+    b = sp.BatchSelfPlay(m, m2, n_slots=8, sims=sims, seed=seed, first_game=first, max_games=8, randomised=True, log_capacity=8 * 600)
+    want2 = _records(b.run_to_completion(max_plies=1100))
+    b.close()
+    b = sp.BatchSelfPlay(m, m2, n_slots=8, sims=sims, seed=seed, first_game=first, max_games=8, randomised=True, log_capacity=8 * 600, free_running=True)
+    assert b.reuse is False
+    got2 = _records(b.run_to_completion(max_plies=1100))
+    b.close()
+    assert got2 == want2
+    with pytest.raises(ValueError):
+        sp.BatchSelfPlay(m, m2, n_slots=2, sims=4, free_running=True, reuse=True)
+
+
 def test_config1_one_whole_game_50_sims_matches_oracle(golden_dir):
     """BASELINE config 1 for real (selfplay.py:155-175): ONE whole game at 50 simulations per move with good_model.h5 through
     the delivered selfplay() on the HIP path, against the CPU oracle playing the same game id with a callback into the same

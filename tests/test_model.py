@@ -13,15 +13,15 @@ sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 
 LOGIT_TOL = 1e-5        # absolute, on logits in [-15, 23] (BASELINE.json north_star)
 # DEVIATION from north_star, stated in DESIGN.md section 5 and set FROM EVIDENCE (round 4): a float32 evaluation (the reference's own
-# Keras floatx) of this 30-layer net differs from a float64 one by more than 1e-5 on a few logits in 10^5 whatever computes it.
-# Measured on the widened fixture -- 4096 self-play positions x the reference's three weight files = 3 612 672 logits
-# (profiles/r4_n1_wide.json): the fused HIP kernel max 2.19e-5, 82 logits >= 1e-5 (2.3e-5 of all), 99.99th percentile 8.7e-6 / 7.5e-6 /
-# 4.5e-6 per weight file, mean 5.6e-7 / 7.5e-7 / 2.9e-7.  The bars: every logit within 1.25 x the measured maximum, >= 99.99 % within
-# 1e-5; values within 1e-5 outright; fp64 mode 1e-9.  On the 256-position fixture (75 264 logits) the kernel's maximum is 1.26e-5:
-# cap 1.25 x that.  The float32 evaluators that are NOT the product path (the PyTorch module on the CPU / through MIOpen, the float32
-# NumPy restatement: max 2.1e-5 on the small fixture) keep the loose cap.
-FP32_CAP_WIDE, FP32_FRACTION_WIDE = 2.75e-5, 0.9999
-FP32_CAP_HIP_SMALL = 1.6e-5
+# Keras floatx) of this 30-layer net differs from a float64 one by more than 1e-5 on a few logits in 10^5 whatever computes it and in
+# whatever order it adds (six segmentations of the accumulation chains measured: profiles/r4_n1_wide_variants.json).  The fused HIP
+# kernel on the widened fixture -- 4096 self-play positions x the reference's three weight files = 3 612 672 logits: max 2.00e-5,
+# 215 logits >= 1e-5 (6.0e-5 of all), mean 6.1e-7 / 8.5e-7 / 3.2e-7 per weight file; on the 256-position fixture (75 264 logits)
+# max 1.11e-5, 4 above.  The bars: every logit within 1.25 x the measured maximum (NOT round 3's 3e-5), >= 99.99 % within 1e-5 on the wide
+# fixture; values within 1e-5 outright; fp64 mode 1e-9.  The float32 evaluators that are NOT the product path (the PyTorch module on
+# the CPU / through MIOpen, the float32 NumPy restatement: max 2.1e-5 on the small fixture already) keep the loose cap.
+FP32_CAP_WIDE, FP32_FRACTION_WIDE = 2.5e-5, 0.9999
+FP32_CAP_HIP_SMALL = 1.4e-5
 FP32_FRACTION, FP32_CAP = 0.999, 3e-5
 
 
@@ -410,7 +410,6 @@ def test_gpu_all_three_weight_files_on_the_wide_fixture(golden_dir):
         lg, v = m.predict_batch(x)
         d = np.abs(lg.double().cpu().numpy() - ref['logits_' + name])
         assert d.max() < FP32_CAP_WIDE and (d < LOGIT_TOL).mean() >= FP32_FRACTION_WIDE and d.mean() < 1e-6, (name, d.max(), (d < LOGIT_TOL).mean())
-        assert np.quantile(d, 0.9999) < LOGIT_TOL, name
         assert np.abs(v.double().cpu().numpy() - ref['v_' + name]).max() < LOGIT_TOL, name
         above, total = above + int((d >= LOGIT_TOL).sum()), total + d.size
         p, _ = m.evaluate_batch(x)
