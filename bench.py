@@ -302,7 +302,7 @@ def config3(args, torch, rank, world, local, barrier):
     k_ms = net_kernel_alone(model, n_pos, torch, local)
     return d, dt, dict(n_pos=n_pos, k_ms=k_ms, parts=parts, weights=os.path.basename(w) if w else 'random-init', backend=model.backend,
                        steps=steps, rows_written=int(rows), file_bytes=size, t_play=t_play, t_drain=t_drain, t_write=t_write,
-                       n_slots=run.n_slots,
+                       n_slots=run.n_slots, free_running=bool(getattr(run, 'free_running', False)),
                        host_cpu_s=(ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime), peak_rss_mb=ru1.ru_maxrss / 1024.0)
 
 
@@ -515,7 +515,13 @@ def main():
                        'measured': {'games_per_s': done / dt3, 'games_won_per_s': tot3['games_won'] / dt3,
                                     'discard_rate': tot3['games_discarded'] / max(done, 1), 'plies_per_game': tot3['plies'] / max(done, 1),
                                     'timed_region_s_total': dt3, 'node_expansions_per_s': ex / dt3,
-                                    'net_evals_per_s': steps * (S + 1) * info['n_slots'] * world / dt3,
+                                    'net_evals_per_s': steps * (S + 1) * info['n_slots'] * world / dt3,      # rows the evaluator launches carried
+                                    'net_evals_asked_per_s': (ex - tot3.get('cache_hits', 0)) / dt3,          # rows that answered a request
+                                    'expansions_from_previous_tree_per_s': tot3.get('cache_hits', 0) / dt3,
+                                    'tree_reuse_hit_rate': tot3.get('cache_hits', 0) / max(ex, 1),
+                                    'terminal_sim_share': tot3['terminal_sims'] / max(tot3['sims'], 1),
+                                    'searched_plies_per_slot_per_step': tot3['mcts_plies'] / max(steps * info['n_slots'] * world, 1),
+                                    'free_running': info['free_running'],
                                     'train_rows_per_s': rows_all / dt3,
                                     'host_cpu_s_per_rank': [h[0] for h in host], 'host_cpu_cores_busy_per_rank': [h[0] / dt3 for h in host],
                                     'host_peak_rss_mb_per_rank': [h[1] for h in host], 'usable_cores': usable_cores()}},

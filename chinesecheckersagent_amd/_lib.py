@@ -25,7 +25,8 @@ CNT_CACHE_HITS = 15
 CNT_COUNT = 16
 ADVANCE_REUSE, ADVANCE_LOG_GUARD = 1, 2
 CNT_NAMES = ['expansions', 'terminal_sims', 'sims', 'plies', 'mcts_plies', 'games_won', 'games_discarded',
-             'sum_depth', 'sum_children', 'select_edges', 'samples', 'errors']
+             'sum_depth', 'sum_children', 'select_edges', 'samples', 'errors', 'cache_hits']
+CNT_INDEX = {name: (i if i < 12 else 15) for i, name in enumerate(CNT_NAMES)}        # cache_hits = CCSP_CNT_CACHE_HITS (15)
 
 STATE_DTYPE = np.dtype([('occ', '<u8', (2,)), ('pos', 'u1', (2, 6)), ('last', 'u1', (4,))])
 META_DTYPE = np.dtype([('game', '<u8'), ('ply', '<u4'), ('player', 'u1'), ('pad', 'u1', (3,))])
@@ -79,6 +80,7 @@ _SIGS = {
     'ccsp_ply_end': (C.c_int, [_VP, _VP]),
     'ccsp_enable_tree_reuse': (C.c_int, [_VP]),
     'ccsp_advance': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
+    'ccsp_boundary': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
     'ccsp_debug_advance_budget': (C.c_int, [C.c_int]),
     'ccsp_read_counters': (C.c_int, [_VP, _VP]),
     'ccsp_read_visit_histogram': (C.c_int, [_VP, _VP]),

@@ -1030,21 +1030,6 @@ __device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot 
     const double s = lds.gam[CCSP_MAX_MOVES];
     for (int i = lane; i < CCSP_NUM_ACTIONS; i += 64) lds.pi[i] = lds.pi[i] / s;
     __syncthreads();
-    // np.random.choice(294, p=pi) stand-in (spec.sample_index): cumsum, / last, first cdf > u
-    if (lane == 0) {
-        const double u = (double)(ccsp_rng_from(sl.hgame, sl.ply, 0, 0, CCSP_P_SAMPLE) >> 11) * 1.1102230246251565e-16;
-        double last = 0.0;
-        for (int i = 0; i < CCSP_NUM_ACTIONS; i++) last = last + lds.pi[i];
-        double c = 0.0; int pick = CCSP_NUM_ACTIONS - 1;
-        for (int i = 0; i < CCSP_NUM_ACTIONS; i++) { c = c + lds.pi[i]; if (c / last > u) { pick = i; break; } }
-        lds.cnt[6] = (uint8_t)(pick / CCSP_NCELL); lds.cnt[7] = (uint8_t)(pick % CCSP_NCELL);
-    }
-    __syncthreads();
-    const int cid = lds.cnt[6], cdest = lds.cnt[7];
-    const uint32_t pick_idx = (uint32_t)(cid * CCSP_NCELL + cdest);
-    const uint64_t f_lo = __ballot(mvs[0] == pick_idx), f_hi = __ballot(mvs[1] == pick_idx);
-    const bool found = (f_lo | f_hi) != 0;                                                        // MCTS.py:141-151
-    if (chosen_child && found) *chosen_child = uni32(blk_child(b, K)[f_lo ? ccsp_ctz64(f_lo) : 64 + ccsp_ctz64(f_hi)]);
     // play_history.append((root.state, pi)) (selfplay.py:128) -> one row of the sample log
     unsigned long long row = 0;
     if (lane == 0) row = atomicAdd(P.log_count, 1ULL);
@@ -1058,6 +1043,37 @@ __device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot 
         double *dst = P.log_pi + row * CCSP_NUM_ACTIONS;
         for (int i = lane; i < CCSP_NUM_ACTIONS; i += 64) dst[i] = lds.pi[i];
     }
+    __syncthreads();
+    // np.random.choice(294, p=pi) stand-in (spec.sample_index): cumsum, / last, first cdf > u.  The running sums are ONE chain of 294
+    // additions in index order (lane 0, in place over pi: the log row is written); the 294 divisions and comparisons do not depend on
+    // one another: every lane tests its own entries and a ballot finds the first index that passes -- the serial scan's pick
+    static_assert(CCSP_NUM_ACTIONS % 6 == 0, "the running sums are unrolled by six");
+    if (lane == 0) {
+        double c = 0.0;
+        for (int i = 0; i < CCSP_NUM_ACTIONS; i += 6) {
+            const double a0 = lds.pi[i], a1 = lds.pi[i + 1], a2 = lds.pi[i + 2], a3 = lds.pi[i + 3], a4 = lds.pi[i + 4], a5 = lds.pi[i + 5];
+            c = c + a0; lds.pi[i] = c; c = c + a1; lds.pi[i + 1] = c; c = c + a2; lds.pi[i + 2] = c;
+            c = c + a3; lds.pi[i + 3] = c; c = c + a4; lds.pi[i + 4] = c; c = c + a5; lds.pi[i + 5] = c;
+        }
+    }
+    __syncthreads();
+    int pick = CCSP_NUM_ACTIONS - 1;
+    {
+        const double u = (double)(ccsp_rng_from(sl.hgame, sl.ply, 0, 0, CCSP_P_SAMPLE) >> 11) * 1.1102230246251565e-16;
+        const double last = lds.pi[CCSP_NUM_ACTIONS - 1];
+        bool seen = false;
+#pragma unroll
+        for (int r = 0; r < (CCSP_NUM_ACTIONS + 63) / 64; r++) {
+            const int i = lane + 64 * r;
+            const uint64_t hit = __ballot(i < CCSP_NUM_ACTIONS && lds.pi[i < CCSP_NUM_ACTIONS ? i : 0] / last > u);
+            if (!seen && hit) { pick = 64 * r + ccsp_ctz64(hit); seen = true; }
+        }
+    }
+    const int cid = pick / CCSP_NCELL, cdest = pick % CCSP_NCELL;
+    const uint32_t pick_idx = (uint32_t)pick;
+    const uint64_t f_lo = __ballot(mvs[0] == pick_idx), f_hi = __ballot(mvs[1] == pick_idx);
+    const bool found = (f_lo | f_hi) != 0;                                                        // MCTS.py:141-151
+    if (chosen_child && found) *chosen_child = uni32(blk_child(b, K)[f_lo ? ccsp_ctz64(f_lo) : 64 + ccsp_ctz64(f_hi)]);
     tl.samples += (row < P.log_cap) ? 1ULL : 0ULL;
     sl.n_hist += 1;
     tl.mcts_plies += 1;
@@ -1456,6 +1472,9 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     uint32_t phase = (uint32_t)(w15 & 0xFF), half = (uint32_t)((w15 >> 8) & 1), root_shadow = (uint32_t)(w15 >> 32);
     const uint32_t kind = uni32(P.pend[g].kind);
     if (phase == 1) return;                               // in a search: advance_kernel's business
+    // A root request is two calls old when its answer is taken: this kernel may run BESIDE the evaluator launch that follows the
+    // call which wrote the planes (the caller's side stream), so that launch's answer is not to be trusted -- the next one's is.
+    if (kind == 4) { if (lane == 0) P.pend[g].kind = 3; return; }
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
     __builtin_amdgcn_s_setprio(2);
@@ -1480,7 +1499,6 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
             const uint64_t game0 = sl.game;
             uint32_t cw = 0;
             wave_finish_ply(P, lds, sl, pool, tl, &cw);
-            fast_forward_opening(P, lds, sl, game0, tl);
             // the ply's tallies -> global counters
             tl.expansions += acc[0]; tl.terminal_sims += acc[1]; tl.sims += acc[2]; tl.sum_depth += acc[3];
             tl.sum_children += acc[4]; tl.select_edges += acc[5];
@@ -1492,8 +1510,9 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
             if (reuse) half ^= 1u;                        // the tree just searched stays where it is; the next ply grows in the other pool
             phase = 0;
         }
-        while (sl.status == CCSP_ST_RUNNING && sl.opening_left > 0) { wave_opening_ply(P, lds, sl, tl); root_shadow = 0; }   // selfplay.py:32-33
-        if (sl.status == CCSP_ST_RUNNING) {
+        // ONE opening ply (selfplay.py:32-33) per call: what a slot does here between two evaluator launches stays short
+        if (sl.status == CCSP_ST_RUNNING && sl.opening_left > 0) { wave_opening_ply(P, lds, sl, tl); root_shadow = 0; }
+        if (sl.status == CCSP_ST_RUNNING && sl.opening_left == 0) {
             if (reuse && root_shadow != 0) {              // the root was a node of the previous ply's tree: its priors and value are there
                 const uint8_t *ob = (half ? P.pool : P.pool2) + (uint64_t)g * P.pool_stride + ((uint64_t)root_shadow << 3);
                 ev.kind = CCSP_EVAL_CACHED; ev.p_edges = reinterpret_cast<const double *>(ob + BLOCK_HDR);
@@ -1501,7 +1520,7 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
                 expand_root = true; hit = 1;
             } else {
                 wave_encode(lds, sl.st, (int)sl.player, planes + (uint64_t)g * CCSP_PLANES);
-                request = 3;
+                request = 4;
             }
         }
     }
@@ -1524,8 +1543,12 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     tally_flush(P, tl);
 }
 
-__global__ __launch_bounds__(64) void advance_kernel(Params P, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, int budget) {
-    __shared__ Lds lds;
+#ifndef CCSP_ADVANCE_WAVES
+#define CCSP_ADVANCE_WAVES 6
+#endif
+__global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params P, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, int budget) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_LIGHT];      // the struct without its last member (pi / gam / rcp: never touched here)
+    Lds &lds = *reinterpret_cast<Lds *>(lds_raw);
     const int g = blockIdx.x, lane = lane_id();
     const uint64_t w15 = uni64(P.slots[g].w[15]);
     uint32_t phase = (uint32_t)(w15 & 0xFF);
@@ -1974,7 +1997,7 @@ int ccsp_enable_tree_reuse(ccsp_ctx *ctx) {
 }
 
 static int g_advance_budget = 4;
-int ccsp_debug_advance_budget(int n) { const int was = g_advance_budget; if (n >= 0) g_advance_budget = n; return was; }
+int ccsp_debug_advance_budget(int n) { const int was = g_advance_budget; if (n >= 1) g_advance_budget = n; return was; }
 
 int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream) {
     if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD))) return CCSP_EINVAL;
@@ -1982,8 +2005,19 @@ int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, 
     if ((flags & CCSP_ADVANCE_REUSE) && !ctx->P.pool2) return CCSP_ESTATE;  // ccsp_enable_tree_reuse first (an allocation: not inside a captured graph)
     if (ctx->phase != 0) return CCSP_ESTATE;                                // not in the middle of a lock-step ply
     CTX_ENTER(ctx, stream);
-    hipLaunchKernelGGL(boundary_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags);
     hipLaunchKernelGGL(advance_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget);
+    CCSP_HIPCHK(hipGetLastError());
+    ctx->opening_plies = -1;
+    return CCSP_OK;
+}
+
+int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream) {
+    if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD))) return CCSP_EINVAL;
+    if (ctx->cfg.mode != CCSP_MODE_SELFPLAY) return CCSP_EINVAL;
+    if ((flags & CCSP_ADVANCE_REUSE) && !ctx->P.pool2) return CCSP_ESTATE;
+    if (ctx->phase != 0) return CCSP_ESTATE;
+    CTX_ENTER(ctx, stream);
+    hipLaunchKernelGGL(boundary_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags);
     CCSP_HIPCHK(hipGetLastError());
     ctx->opening_plies = -1;
     return CCSP_OK;

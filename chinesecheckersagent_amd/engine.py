@@ -99,11 +99,18 @@ class SelfPlayEngine(object):
         check(self.L.ccsp_enable_tree_reuse(self.ctx), 'ccsp_enable_tree_reuse')
 
     def advance(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stream=None):
-        """every slot: take the answer (p, v) to its last request, go on to its next one (planes out)"""
+        """slots in a search: take the answer (p, v) to the leaf they asked about, go on to their next request (planes out)"""
         self._check_pv(p, v)
         flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0)
         check(self.L.ccsp_advance(self.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(),
                                   model_sel.data_ptr() if model_sel is not None else None, flags, _stream_ptr(stream)), 'ccsp_advance')
+
+    def boundary(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stream=None):
+        """slots between two searches: root expansion from the answer, or the finished ply's move and rules and the next ply's root"""
+        self._check_pv(p, v)
+        flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0)
+        check(self.L.ccsp_boundary(self.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(),
+                                   model_sel.data_ptr() if model_sel is not None else None, flags, _stream_ptr(stream)), 'ccsp_boundary')
 
     def _check_pv(self, p, v):
         import torch
@@ -114,9 +121,7 @@ class SelfPlayEngine(object):
     def counters(self):
         out = np.zeros(CNT_COUNT, dtype=np.uint64)
         check(self.L.ccsp_read_counters(self.ctx, out.ctypes.data), 'ccsp_read_counters')
-        d = {name: int(out[i]) for i, name in enumerate(CNT_NAMES)}
-        d['cache_hits'] = int(out[_lib.CNT_CACHE_HITS])
-        return d
+        return {name: int(out[_lib.CNT_INDEX[name]]) for name in CNT_NAMES}
 
     def visit_histogram(self):
         out = np.zeros(NUM_ACTIONS, dtype=np.uint64)

@@ -157,6 +157,10 @@ class BatchSelfPlay(object):
             _warn('hipGraph capture of the simulation steps failed (%r): this batch runs on plain launches' % (ex,))
 
     # ---- free-running stepping ---------------------------------------------------------------------------------------------
+    FREE_UNROLL = 25         # [net -> advance | boundary] rounds per captured hipGraph
+    SIDE_STREAM = False      # ccsp_boundary on a stream of its own beside the next evaluator launch (measured: hipGraphs with forks
+                             # stop overlapping the two half-batches' graphs; kept for experiments)
+
     def _evaluate_free(self):
         p, v = self.m1.evaluate_batch(self.planes)
         if self.m2 is not None:                            # the request names the model: player two's searches ask model2 (selfplay.py:30,36,59)
@@ -166,8 +170,24 @@ class BatchSelfPlay(object):
             v = self.torch.where(sel, v2, v)
         return p.contiguous(), v.contiguous()
 
-    def _advance(self, p, v):
-        self.eng.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
+    def _round(self, p, v, capturing=False):
+        """the tree's share of a step, after the evaluator launch that produced (p, v) has been issued on the current stream:
+        ccsp_advance there (the slots in a search), ccsp_boundary on a side stream (the few slots between two searches: the end of a
+        ply is long -- pi, sampling, rules, Dirichlet noise -- and runs beside the NEXT evaluator launch instead of in front of it)"""
+        torch, e = self.torch, self.eng
+        if not self.SIDE_STREAM:
+            e.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
+            e.boundary(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
+            return
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self._side)                        # the previous round's boundary work: done before this round's advance
+        e.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            e.boundary(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
+        if not capturing:
+            p.record_stream(self._side)
+            v.record_stream(self._side)
 
     def _capture_free(self):
         torch = self.torch
@@ -178,14 +198,15 @@ class BatchSelfPlay(object):
                 for _ in range(2):
                     self._evaluate_free()
             torch.cuda.current_stream().wait_stream(s)
-            self._unroll = 25
+            self._unroll = self.FREE_UNROLL
             keep = []
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):                      # capture only: nothing executes here
                 for _ in range(self._unroll):
                     gp, gv = self._evaluate_free()
-                    self._advance(gp, gv)
+                    self._round(gp, gv, capturing=True)
                     keep.append((gp, gv))
+                torch.cuda.current_stream().wait_stream(self._side)      # the side stream joins before the capture ends
             self._graph, self._graph_out = g, keep
         except Exception as ex:
             self.use_graph = False
@@ -197,8 +218,10 @@ class BatchSelfPlay(object):
     def play_steps(self, n):
         """n steps of [one batched forward of the net -> ccsp_advance]"""
         assert self.free_running
+        torch = self.torch
         if not self._started:
-            self._advance(self._p0, self._v0)              # nothing is pending yet: every slot starts its game and leaves its first request
+            self._side = torch.cuda.Stream(device=self.planes.device)
+            self._round(self._p0, self._v0)                # nothing is pending yet: every slot starts its game
             self._started = True
         if self.use_graph and self._graph is None:
             self._capture_free()
@@ -209,8 +232,9 @@ class BatchSelfPlay(object):
                 done += self._unroll
         while done < n:
             p, v = self._evaluate_free()
-            self._advance(p, v)
+            self._round(p, v)
             done += 1
+        torch.cuda.current_stream().wait_stream(self._side)
         self.steps += n
 
     def play_ply(self):

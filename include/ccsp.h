@@ -243,27 +243,35 @@ int ccsp_expand_backup(ccsp_ctx *ctx, const double *p, const float *v, void *str
 int ccsp_expand_backup_select(ccsp_ctx *ctx, const double *p, const float *v, float *planes, void *stream);
 int ccsp_ply_end(ccsp_ctx *ctx, void *stream);
 
-/* Free-running stepped path (self-play mode): the same search, every slot at its own simulation of its own ply.  One call =
- * for every slot: take the answer (p[slot], v[slot]) to the request the slot left in the previous call (a leaf to expand,
- * MCTS.py:93-118, or a ply's root, selfplay.py:117-124), then go on -- end the ply when its `sims` simulations are done (MCTS.py:127-153,
- * selfplay.py:38-74), play opening plies (selfplay.py:83-104), start the next ply, select (MCTS.py:49-76) -- until the slot needs the
- * evaluator again: planes[slot] out, request recorded.  The caller's loop is [evaluate planes -> ccsp_advance] for ever; the first call
- * finds no request and only emits.  Simulations that end in a won leaf (MCTS.py:81-90) never wait for the evaluator.
+/* Free-running stepped path (self-play mode): the same search, every slot at its own simulation of its own ply.  The caller's loop is
+ *     for ever: [evaluate planes -> (p, v)]  ->  ccsp_advance(p, v)  ->  ccsp_boundary(p, v)
+ * (the very first round has no answer to give: any p, v).  Per slot, a call takes the answer to the request the slot left earlier and
+ * goes on until it needs the evaluator again -- planes[slot] out, request recorded:
+ *   ccsp_advance    slots in a search: expansion + backup of the answered leaf (MCTS.py:93-118), then selection (MCTS.py:49-76) --
+ *                   and on through simulations that end in a won leaf (MCTS.py:81-90) and through reused positions -- until a leaf needs
+ *                   the evaluator, or the ply's `sims` simulations are done;
+ *   ccsp_boundary   slots between two searches: root expansion + Dirichlet noise from the answer (selfplay.py:117-124), or: pi, the move,
+ *                   the end-of-ply rules and the log row of the finished ply (MCTS.py:127-153, selfplay.py:38-74), one opening ply
+ *                   (selfplay.py:83-104), the next ply's root -- expanded from the previous tree (reuse) or its planes out as a request.
+ *                   It may run on ANOTHER stream beside the next evaluator launch, provided it starts after the ccsp_advance of its round
+ *                   and ends before the ccsp_advance of the next (the few slots it serves are not in a search; a root request is therefore
+ *                   answered by the evaluator launch AFTER the next one).
  *   CCSP_ADVANCE_REUSE      selfplay.make_move returns the chosen child as a fresh root (selfplay.py:130-133) and the next ply evaluates the
  *                           positions of its subtree again; with this flag a position the previous ply's tree holds below the move that was
  *                           played is expanded from that tree's priors and value -- the evaluator is a function of the position alone, so
  *                           trees, pi and games are bit-identical, only the evaluator is asked less often (CCSP_CNT_CACHE_HITS).  Needs
  *                           ccsp_enable_tree_reuse (a second tree pool).  NOT for two-model games: the previous ply was searched with the
- *                           other player's model (selfplay.py:30,59).
+ *                           other player's model (selfplay.py:30,59).  The same flags go to both calls.
  *   CCSP_ADVANCE_LOG_GUARD  a slot whose finished ply might not find a free row in the sample log waits for the caller's next
  *                           ccsp_log_clear instead of ending its game in CCSP_ST_ERROR (for callers that harvest the log as they go).
  * model_sel (device, [n_slots], may be NULL): 1 where the request is to be answered by player two's model (selfplay.py:30,36,59).
- * Slots that ask for nothing in a call (game over, budget of evaluator-free simulations spent) ignore their row of the next answer. */
+ * Slots that ask for nothing in a round (game over, budget of evaluator-free simulations spent) ignore their row of the next answer. */
 enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2 };
 int ccsp_enable_tree_reuse(ccsp_ctx *ctx);
 int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
+int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
 /* evaluator-free simulations (won leaves, reused positions) a slot may complete in ONE ccsp_advance (default 4: bounds the launch's
- * length; results do not depend on it).  Returns the previous value; n < 0 only reads it. */
+ * length; results do not depend on it; at least 1: a slot must be able to get past a won leaf).  Returns the previous value; n < 1 only reads it. */
 int ccsp_debug_advance_budget(int n);
 
 /* ---- evaluator: the policy/value network as one fused kernel (row N1; Model.predict, model.py:21-24) ---- */

@@ -407,7 +407,7 @@ def test_free_running_slots_play_the_lock_step_games(golden_dir):
     assert any(h is None for h, _ in want) and sum(isinstance(h, list) for h, _ in want) > n // 2 and cw['cache_hits'] == 0
     was = L.ccsp_debug_advance_budget(-1)
     try:
-        for budget, reuse, graph in ((4, True, True), (0, True, True), (1, True, False), (64, True, True), (4, False, True)):
+        for budget, reuse, graph in ((4, True, True), (1, True, True), (2, True, False), (64, True, True), (4, False, True)):
             L.ccsp_debug_advance_budget(budget)
             b = sp.BatchSelfPlay(m, n_slots=n, sims=sims, seed=seed, first_game=first, max_games=n, log_capacity=n * 600,
                                  free_running=True, reuse=reuse, use_graph=graph)

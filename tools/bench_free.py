@@ -15,8 +15,12 @@ ap.add_argument('--games', type=int, default=4096)
 ap.add_argument('--sims', type=int, default=400)
 ap.add_argument('--lockstep', action='store_true')
 ap.add_argument('--no-reuse', action='store_true')
+ap.add_argument('--side', action='store_true')
+ap.add_argument('--unroll', type=int, default=25)
 a = ap.parse_args()
 os.environ['CCSP_STRICT'] = '1'
+sp.BatchSelfPlay.SIDE_STREAM = a.side
+sp.BatchSelfPlay.FREE_UNROLL = a.unroll
 m = ResidualCNN()
 m.load_weights('tests/golden/good_model.h5')
 L = _lib.lib()
