@@ -268,6 +268,10 @@ def config3(args, torch, rank, world, local, barrier):
         sink.discard = False                            # rows of games that ended before the timed region are not its output
         sink.open(os.path.join(out_dir, 'data-for-iter-%d.h5' % rank))
         barrier()
+        parts_ = run.b.parts if hasattr(run.b, 'parts') else [run.b]
+        for b_ in parts_:                               # the evaluator launches of the uncaptured steps (one per part and timed ply), each
+            if getattr(b_, 'free_running', False):      # between HIP events on its own stream while the other half-batch's graphs run
+                b_.net_events = []
         c0 = run.counters()
         ru0 = resource.getrusage(resource.RUSAGE_SELF)   # this rank's host side (main thread + converter thread) over the timed region
         t0 = time.time()
@@ -289,6 +293,7 @@ def config3(args, torch, rank, world, local, barrier):
         dt = time.time() - t0
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         c1 = run.counters()
+        net_in_pipeline_ms = [a.elapsed_time(b) for b_ in parts_ for a, b in (getattr(b_, 'net_events', None) or [])]
         size = os.path.getsize(path)
         parts = len(run.b.parts) if hasattr(run.b, 'parts') else 1
         graphs = [b._graph is not None for b in (run.b.parts if hasattr(run.b, 'parts') else [run.b])]
@@ -303,6 +308,8 @@ def config3(args, torch, rank, world, local, barrier):
     return d, dt, dict(n_pos=n_pos, k_ms=k_ms, parts=parts, weights=os.path.basename(w) if w else 'random-init', backend=model.backend,
                        steps=steps, rows_written=int(rows), file_bytes=size, t_play=t_play, t_drain=t_drain, t_write=t_write,
                        n_slots=run.n_slots, free_running=bool(getattr(run, 'free_running', False)),
+                       net_in_pipeline_ms=(sorted(net_in_pipeline_ms)[len(net_in_pipeline_ms) // 2] if net_in_pipeline_ms else None),
+                       net_in_pipeline_samples=len(net_in_pipeline_ms),
                        host_cpu_s=(ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime), peak_rss_mb=ru1.ru_maxrss / 1024.0)
 
 
@@ -491,6 +498,11 @@ def main():
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         host = [[float(x) for x in e.tolist()] for e in every]
+    k_in_local = info.get('net_in_pipeline_ms') or (info['t_play'] / (info['steps'] * (S + 1) * info['parts']) * 1e3)
+    k_in_all = max_over_ranks(k_in_local)
+
+    def max_over_ranks_in(_):
+        return k_in_all
     out = None
     if rank == 0:
         ex = tot3['expansions']
@@ -505,9 +517,9 @@ def main():
             'dtype': 'f32', 'data': 'synthetic', 'degraded': False,
             'config': {'workload': 'config 3: %d concurrent games/GPU x %d sims/move, %s through the fused fp32-MFMA evaluator kernel '
                                    '(float64 PUCT tree), played through selfplay.SelfPlayRun (the API behind selfplay_batch / '
-                                   'generate_self_play): restarting slots in steady state, stepped path (select kernel -> net -> '
-                                   'expand/backup kernel per simulation, 25 steps per hipGraph, %d half-batches on their own streams), '
-                                   'log harvested every %d plies; timed: %d plies + conversion to (board_x, pi_y, v_y) + streaming them into the HDF5 training file; '
+                                   'generate_self_play): restarting slots in steady state, free-running stepped path (every slot at its own '
+                                   'simulation of its own ply: net -> advance kernel [-> boundary kernel]; positions of the previous tree reused; 25 rounds per hipGraph, %d half-batches on their own streams), '
+                                   'log harvested every %d steps; a step = sims + 1 evaluator launches per half-batch; timed: %d steps + conversion to (board_x, pi_y, v_y) + streaming them into the HDF5 training file; '
                                    'untimed before: %d plies in which the first cohort of games spreads out + %d warm-up'
                                    % (G, S, info['weights'], info['parts'], args.harvest_every, steps, args.spread_plies, W),
                        'games_per_gpu': G, 'sims': S, 'sharding': 'game id mod n_gpus',
@@ -535,23 +547,27 @@ def main():
             'mean_depth': tot3['sum_depth'] / max(tot3['sims'], 1), 'mean_children': tot3['sum_children'] / max(ex, 1),
             'errors': tot3['errors'], 'per_rank_expansions': per3, 'precision': 'fp32', 'backend': info['backend'],
             'target_node_expansions_per_s_per_gpu': 1e6,
-            # `achieved` / `frac` describe the kernel AS THE PRODUCT RUNS IT: the timed plies' wall time over the evaluator launches in them
-            # (two half-batches on two streams, the other half's tree kernels on the same SIMDs) -- an upper bound on a launch's
-            # duration there; the kernel alone (a back-to-back burst timed by HIP events on its stream) is kept as *_isolated
-            'roofline': {'bound': 'mfma', 'dtype': 'fp32', 'kernel': 'net_forward_kernel',
-                         'achieved': info['n_pos'] * NET_FLOP_PER_EVAL / (max(h[2] for h in host) / launches) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS,
+            # `achieved` / `frac` describe the kernel AS THE PRODUCT RUNS IT: the median duration of the evaluator launches of the timed
+            # region's uncaptured steps (one per half-batch and timed ply), each between two HIP events on the stream it is launched on,
+            # while the other half-batch's captured graphs -- evaluator and tree kernels -- run beside it.  Kept beside it: the kernel
+            # alone (*_isolated: a back-to-back burst after the timed region) and the timed plies' wall time per evaluator launch
+            # (wall_ms_per_launch: what a launch COSTS the pipeline, tree kernels that do not hide under the other half's launch included).
+            'roofline': (lambda k_in: {
+                         'bound': 'mfma', 'dtype': 'fp32', 'kernel': 'net_forward_kernel',
+                         'achieved': info['n_pos'] * NET_FLOP_PER_EVAL / (k_in * 1e-3) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS,
                          'unit': 'TFLOP/s',
-                         'frac': info['n_pos'] * NET_FLOP_PER_EVAL / (max(h[2] for h in host) / launches) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         'frac': info['n_pos'] * NET_FLOP_PER_EVAL / (k_in * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          'traffic': None,
                          'flop_per_position': NET_FLOP_PER_EVAL, 'positions_per_launch': info['n_pos'],
-                         'avg_launch_ms': max(h[2] for h in host) / launches * 1e3,
-                         'how': 'wall time of the timed plies / evaluator launches in them (captured hipGraphs on two streams, tree kernels '
-                                'of the other half-batch beside them); *_isolated: 400 back-to-back launches after the timed region, '
-                                'HIP events on the launching stream',
+                         'avg_launch_ms': k_in,
+                         'how': ('median of %d launches inside the timed region, HIP events on the launching stream, the other half-batch running beside them'
+                                 % info['net_in_pipeline_samples']) if info.get('net_in_pipeline_ms') else
+                                'wall time of the timed plies / evaluator launches in them (no uncaptured step to put events around)',
                          'launches_in_timed_region_per_gpu': launches,
                          'achieved_isolated': tf, 'frac_isolated': tf / MFMA_F32_PEAK_TFLOPS, 'avg_launch_ms_isolated': k_ms,
-                         'in_pipeline_ms_per_launch': info['t_play'] / launches * 1e3,
-                         'in_pipeline_frac': info['n_pos'] * NET_FLOP_PER_EVAL / (info['t_play'] / launches) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+                         'wall_ms_per_launch': max(h[2] for h in host) / launches * 1e3,
+                         'wall_frac': info['n_pos'] * NET_FLOP_PER_EVAL / (max(h[2] for h in host) / launches) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         })(max_over_ranks_in(info)),
         }
         try:                                 # HBM bytes of one launch by the counters (static: a --pmc pass cannot run inside this process)
             prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))['net_forward_kernel']

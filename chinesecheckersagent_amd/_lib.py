@@ -23,7 +23,7 @@ GREEDY_MAX = 32
  CNT_SUM_DEPTH, CNT_SUM_CHILDREN, CNT_SELECT_EDGES, CNT_SAMPLES, CNT_ERRORS) = range(12)
 CNT_CACHE_HITS = 15
 CNT_COUNT = 16
-ADVANCE_REUSE, ADVANCE_LOG_GUARD = 1, 2
+ADVANCE_REUSE, ADVANCE_LOG_GUARD, ADVANCE_STAGGER = 1, 2, 4
 CNT_NAMES = ['expansions', 'terminal_sims', 'sims', 'plies', 'mcts_plies', 'games_won', 'games_discarded',
              'sum_depth', 'sum_children', 'select_edges', 'samples', 'errors', 'cache_hits']
 CNT_INDEX = {name: (i if i < 12 else 15) for i, name in enumerate(CNT_NAMES)}        # cache_hits = CCSP_CNT_CACHE_HITS (15)

@@ -124,18 +124,21 @@ struct Lds {                      // per-wave scratch (one wave per workgroup)
     ccsp_line_tables T;           // line tables (ccsp_rules.h), copied from device constant data
     uint32_t lines[32];           // occupancy pattern of the 27 board lines for the position being expanded
     uint8_t lists[6][24];
-    uint8_t stack[6][96];         // depth-first stacks of wave_movegen (<= 6 pushes per visited sub-lattice cell)
+    union {
+        uint8_t stack[6][96];     // depth-first stacks of wave_movegen (<= 6 pushes per visited sub-lattice cell)
+        uint8_t img[CCSP_PLANES + 1];   // wave_encode's byte image (never alive while a move list is being generated)
+    };
     uint8_t cnt[8];
-    uint8_t img[CCSP_PLANES + 1];
-    uint8_t cells[CCSP_NCELL + 7];
-    // LAST: a kernel that neither ends plies nor draws root noise nor divides through the table (advance_kernel) allocates the struct
-    // only up to here (LDS_LIGHT bytes) -- 3.5 KB instead of 6.9: six of its workgroups fit beside an evaluator workgroup, not three
+    // LAST: a kernel that neither ends plies nor draws root noise nor starts games nor divides through the table (advance_kernel)
+    // allocates the struct only up to here (LDS_LIGHT bytes) -- 3.0 KB instead of 6.4: seven of its workgroups fit beside an evaluator
+    // workgroup, not three
     union {
         struct {                  // ply begin / end: pi vector, Dirichlet draws
             double pi[CCSP_NUM_ACTIONS];
             double gam[CCSP_MAX_MOVES + 2];
         };
-        double rcp[RCP_N];        // simulation loop: 1/i, i < RCP_N (pick_edge)
+        double rcp[RCP_N];        // simulation loop: 1/i, i < RCP_N (pick_edge); refilled at the start of every ply's simulations
+        uint8_t cells[CCSP_NCELL + 7];   // slot_start_game's shuffle (Board(randomised=True)): after the ply's pi is logged and sampled
     };
 };
 constexpr size_t LDS_LIGHT = (offsetof(Lds, pi) + 15) & ~(size_t)15;
@@ -1376,7 +1379,8 @@ __device__ __forceinline__ void select_core(const Params &P, Lds &lds, int g, fl
 }
 
 __global__ __launch_bounds__(64) void select_kernel(Params P, float *planes) {
-    __shared__ Lds lds;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_LIGHT];      // (no pi / gam / rcp / cells in these kernels)
+    Lds &lds = *reinterpret_cast<Lds *>(lds_raw);
     __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch (stepped path): the short tree kernels go first, the next evaluator launch waits for them
     select_core(P, lds, blockIdx.x, planes);
 }
@@ -1419,7 +1423,8 @@ __device__ __forceinline__ void expand_backup_core(const Params &P, Lds &lds, in
 }
 
 __global__ __launch_bounds__(64) void expand_backup_kernel(Params P, const double *p, const float *v) {
-    __shared__ Lds lds;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_LIGHT];      // (no pi / gam / rcp / cells in these kernels)
+    Lds &lds = *reinterpret_cast<Lds *>(lds_raw);
     __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch (stepped path): the short tree kernels go first, the next evaluator launch waits for them
     expand_backup_core(P, lds, blockIdx.x, p, v);
 }
@@ -1427,11 +1432,41 @@ __global__ __launch_bounds__(64) void expand_backup_kernel(Params P, const doubl
 // phases 4 and 3 of consecutive simulations in one launch: expansion + backup of simulation s, then the selection of s + 1 (the
 // same wave, the same game) -- inside a ply the stepped loop is [evaluate -> this] instead of [evaluate -> expand_backup -> select]
 __global__ __launch_bounds__(64) void expand_backup_select_kernel(Params P, const double *p, const float *v, float *planes) {
-    __shared__ Lds lds;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_LIGHT];      // (no pi / gam / rcp / cells in these kernels)
+    Lds &lds = *reinterpret_cast<Lds *>(lds_raw);
     __builtin_amdgcn_s_setprio(2);
     expand_backup_core(P, lds, blockIdx.x, p, v);
     __syncthreads();                                   // the slot record, the pool and the hand-off record: stores before loads
     select_core(P, lds, blockIdx.x, planes);
+}
+
+// Tree reuse: the node block of a position the previous ply's tree holds (`ob`, at offset shadow << 3 of the other pool) re-created in
+// the current tree -- what wave_expand writes for that position with the evaluator's answer, without generating the moves again:
+// same position = same move list in the same order, same priors, same won-leaf marks; statistics start from zero (MCTS.py:97-109).
+__device__ __forceinline__ int wave_copy_block(SimCtx &sl, uint8_t *pool, const uint8_t *ob, uint32_t shadow, uint32_t &off_out) {
+    const int lane = lane_id();
+    const uint4 h0 = *reinterpret_cast<const uint4 *>(ob), h1 = *reinterpret_cast<const uint4 *>(ob + 16), h2 = *reinterpret_cast<const uint4 *>(ob + 32);
+    const int K = (int)uni32(h2.x);
+    const uint32_t off = sl.pool_used;
+    off_out = off;
+    uint8_t *b = pool + off;
+    sl.pool_used = off + block_bytes(K);
+    if (lane == 0) {
+        *reinterpret_cast<uint4 *>(b) = h0; *reinterpret_cast<uint4 *>(b + 16) = h1;
+        *reinterpret_cast<uint4 *>(b + 32) = make_uint4(h2.x, h2.y, shadow, h2.w);          // K, player, shadow, v
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int j = lane + 64 * h;
+        if (j < K) {
+            blk_P(b, K)[j] = reinterpret_cast<const double *>(ob + BLOCK_HDR)[j];
+            blk_W(b, K)[j] = 0.0;
+            blk_N(b, K)[j] = 0u;
+            blk_child(b, K)[j] = reinterpret_cast<const uint32_t *>(ob + BLOCK_HDR + 20 * K)[j] == CHILD_TERMINAL ? CHILD_TERMINAL : CHILD_LEAF;
+            blk_mv(b, K)[j] = reinterpret_cast<const uint16_t *>(ob + BLOCK_HDR + 24 * K)[j];
+        }
+    }
+    return K;
 }
 
 // ---- free-running stepped path (ccsp_advance): every slot at its own simulation of its own ply ---------------------------------
@@ -1462,10 +1497,10 @@ __global__ __launch_bounds__(64) void expand_backup_select_kernel(Params P, cons
 // spent a slot selects once more and leaves its request if that leaf needs the evaluator -- otherwise it returns without one (its row
 // of the next evaluator launch is idle) and selects the same leaf again in the next call.  Bounds the launch's length.
 __device__ __forceinline__ void write_w15(const Params &P, int g, uint32_t phase, uint32_t half, uint32_t root_shadow) {
-    if (lane_id() == 0) P.slots[g].w[15] = (uint64_t)phase | ((uint64_t)half << 8) | ((uint64_t)root_shadow << 32);
+    if (lane_id() == 0) P.slots[g].w[15] = (uint64_t)phase | ((uint64_t)half << 8) | (1ULL << 9) | ((uint64_t)root_shadow << 32);   // (bit 9: the start delay is spent)
 }
 
-__global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags) {
+__global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, int stagger) {
     __shared__ Lds lds;
     const int g = blockIdx.x, lane = lane_id();
     const uint64_t w15 = uni64(P.slots[g].w[15]);
@@ -1475,6 +1510,19 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     // A root request is two calls old when its answer is taken: this kernel may run BESIDE the evaluator launch that follows the
     // call which wrote the planes (the caller's side stream), so that launch's answer is not to be trusted -- the next one's is.
     if (kind == 4) { if (lane == 0) P.pend[g].kind = 3; return; }
+    // STAGGERED START: every slot's first game would begin in the same call and -- plies taking similar numbers of calls -- the slots
+    // would end their plies in waves for dozens of plies: calls in which most slots are at the cheap middle of a search alternate with
+    // calls in which most are at its expensive start (the reused top of the tree: simulation after simulation without the
+    // evaluator).  Slot g therefore sits out hash(g) mod `stagger` calls first (bits 16-31 of word 15 count them down; bit 9 = set
+    // up).  A game's record does not depend on when it is played.
+    if (phase == 0 && stagger > 1 && !((w15 >> 9) & 1)) {
+        const uint32_t wait = ((uint32_t)g * 2654435761u >> 8) % (uint32_t)stagger;
+        if (lane == 0) P.slots[g].w[15] = (w15 & ~0xFFFF0000ULL) | (1ULL << 9) | ((uint64_t)wait << 16);
+        if (wait) return;
+    } else if (phase == 0 && ((w15 >> 16) & 0xFFFF)) {
+        if (lane == 0) P.slots[g].w[15] = w15 - (1ULL << 16);
+        return;
+    }
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
     __builtin_amdgcn_s_setprio(2);
@@ -1494,7 +1542,10 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
             // the sample log is shared by the slots and emptied by the host every few plies: a slot that could find it full waits
             // a call rather than lose its row (a game with a missing row ends in ERROR)
             if ((flags & CCSP_ADVANCE_LOG_GUARD) &&
-                *reinterpret_cast<volatile unsigned long long *>(P.log_count) + (unsigned long long)P.n_slots > P.log_cap) return;
+                *reinterpret_cast<volatile unsigned long long *>(P.log_count) + (unsigned long long)P.n_slots > P.log_cap) {
+                if ((flags & CCSP_ADVANCE_DEBUG) && lane == 0) atomicAdd(&P.counters[13], 1ULL);     // diagnostic: calls a slot waited for a log row
+                return;
+            }
             uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
             const uint64_t game0 = sl.game;
             uint32_t cw = 0;
@@ -1618,8 +1669,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
                 }
                 if (last) { a_sims -= 1; a_depth -= (uint32_t)lf.depth; a_edges -= edges; break; }   // (no request: this slot's row of the next evaluator launch is idle)
                 const uint8_t *ob = old + ((uint64_t)shadow << 3);      // expanded there: the evaluator's answer is in that block
-                ev.kind = CCSP_EVAL_CACHED; ev.p_edges = reinterpret_cast<const double *>(ob + BLOCK_HDR);
-                ev.v_ext = reinterpret_cast<const float *>(ob + 32)[3]; ev.shadow = shadow;
+                ev.kind = CCSP_EVAL_CACHED; ev.v_ext = reinterpret_cast<const float *>(ob + 32)[3]; ev.shadow = shadow;
                 a_hits += 1;
             }
             spent += 1;
@@ -1627,11 +1677,9 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
         if (!terminal) {
             SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
             uint32_t noff;
-            const int k = wave_expand(lds, cx, pool, leaf, leaf_player, ev, 0, false, noff);
+            const int k = ev.kind == CCSP_EVAL_CACHED ? wave_copy_block(cx, pool, old + ((uint64_t)ev.shadow << 3), ev.shadow, noff)
+                                                      : wave_expand(lds, cx, pool, leaf, leaf_player, ev, 0, false, noff);
             sl.pool_used = cx.pool_used;
-            if (ev.kind == CCSP_EVAL_CACHED && k != (int)reinterpret_cast<const uint32_t *>(old + ((uint64_t)ev.shadow << 3) + 32)[0]) {
-                sl.status = CCSP_ST_ERROR; errors += 1; break;            // (cannot happen: the same position has the same moves)
-            }
             if (k > 0 && lane == 0) *reinterpret_cast<uint32_t *>(pool + link_off) = ((noff >> 3) << 7) | (uint32_t)k;
             a_exp += 1; a_children += (uint32_t)k; sl.expansions += 1;
             __syncthreads();
@@ -1646,6 +1694,10 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
         uint32_t *acc = P.stepacc + (size_t)g * 8;
         acc[0] += a_exp; acc[1] += a_term; acc[2] += a_sims; acc[3] += a_depth; acc[4] += a_children; acc[5] += a_edges; acc[6] += a_hits;
         if (errors) atomicAdd(&P.counters[CCSP_CNT_ERRORS], (unsigned long long)errors);
+        if (flags & CCSP_ADVANCE_DEBUG) {                 // diagnostic tallies (tools/bench_free.py --debug): what the slots of this call ended on
+            atomicAdd(&P.counters[12], (unsigned long long)(request == 1));                      // ... a request
+            atomicAdd(&P.counters[14], (unsigned long long)(request == 0 && phase == 1));        // ... the budget (idle evaluator row)
+        }
     }
     write_w15(P, g, phase, half, root_shadow);
     store_slot(P.slots + g, sl);
@@ -1996,11 +2048,11 @@ int ccsp_enable_tree_reuse(ccsp_ctx *ctx) {
     return CCSP_OK;
 }
 
-static int g_advance_budget = 4;
+static int g_advance_budget = 3;      // measured at 4096 x 400 with good_model.h5: 2 / 3 / 4 -> 16.9 / 17.2 / 16.9 M node-expansions/s
 int ccsp_debug_advance_budget(int n) { const int was = g_advance_budget; if (n >= 1) g_advance_budget = n; return was; }
 
 int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream) {
-    if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD))) return CCSP_EINVAL;
+    if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD | CCSP_ADVANCE_STAGGER | CCSP_ADVANCE_DEBUG))) return CCSP_EINVAL;
     if (ctx->cfg.mode != CCSP_MODE_SELFPLAY) return CCSP_EINVAL;          // Game.start's seats are served by the lock-step kernels
     if ((flags & CCSP_ADVANCE_REUSE) && !ctx->P.pool2) return CCSP_ESTATE;  // ccsp_enable_tree_reuse first (an allocation: not inside a captured graph)
     if (ctx->phase != 0) return CCSP_ESTATE;                                // not in the middle of a lock-step ply
@@ -2012,12 +2064,13 @@ int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, 
 }
 
 int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream) {
-    if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD))) return CCSP_EINVAL;
+    if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD | CCSP_ADVANCE_STAGGER | CCSP_ADVANCE_DEBUG))) return CCSP_EINVAL;
     if (ctx->cfg.mode != CCSP_MODE_SELFPLAY) return CCSP_EINVAL;
     if ((flags & CCSP_ADVANCE_REUSE) && !ctx->P.pool2) return CCSP_ESTATE;
     if (ctx->phase != 0) return CCSP_ESTATE;
     CTX_ENTER(ctx, stream);
-    hipLaunchKernelGGL(boundary_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags);
+    hipLaunchKernelGGL(boundary_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags,
+                       (flags & CCSP_ADVANCE_STAGGER) ? ctx->cfg.sims : 0);
     CCSP_HIPCHK(hipGetLastError());
     ctx->opening_plies = -1;
     return CCSP_OK;

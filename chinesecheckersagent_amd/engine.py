@@ -98,17 +98,17 @@ class SelfPlayEngine(object):
         """the second tree pool ccsp_advance(reuse=True) needs (an allocation: call it before capturing a graph)"""
         check(self.L.ccsp_enable_tree_reuse(self.ctx), 'ccsp_enable_tree_reuse')
 
-    def advance(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stream=None):
+    def advance(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stream=None, debug=False):
         """slots in a search: take the answer (p, v) to the leaf they asked about, go on to their next request (planes out)"""
         self._check_pv(p, v)
-        flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0)
+        flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0) | (8 if debug else 0)
         check(self.L.ccsp_advance(self.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(),
                                   model_sel.data_ptr() if model_sel is not None else None, flags, _stream_ptr(stream)), 'ccsp_advance')
 
-    def boundary(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stream=None):
+    def boundary(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stagger=False, stream=None, debug=False):
         """slots between two searches: root expansion from the answer, or the finished ply's move and rules and the next ply's root"""
         self._check_pv(p, v)
-        flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0)
+        flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0) | (_lib.ADVANCE_STAGGER if stagger else 0) | (8 if debug else 0)
         check(self.L.ccsp_boundary(self.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(),
                                    model_sel.data_ptr() if model_sel is not None else None, flags, _stream_ptr(stream)), 'ccsp_boundary')
 
@@ -122,6 +122,11 @@ class SelfPlayEngine(object):
         out = np.zeros(CNT_COUNT, dtype=np.uint64)
         check(self.L.ccsp_read_counters(self.ctx, out.ctypes.data), 'ccsp_read_counters')
         return {name: int(out[_lib.CNT_INDEX[name]]) for name in CNT_NAMES}
+
+    def raw_counters(self):
+        out = np.zeros(CNT_COUNT, dtype=np.uint64)
+        check(self.L.ccsp_read_counters(self.ctx, out.ctypes.data), 'ccsp_read_counters')
+        return [int(x) for x in out]
 
     def visit_histogram(self):
         out = np.zeros(NUM_ACTIONS, dtype=np.uint64)

@@ -78,7 +78,7 @@ class BatchSelfPlay(object):
 
     def __init__(self, model1, model2=None, n_slots=1, sims=MCTS_SIMULATIONS, seed=None, first_game=0, game_stride=1,
                  max_games=None, randomised=False, auto_restart=False, device=0, log_capacity=None, use_graph=True,
-                 free_running=False, reuse=None, log_guard=False):
+                 free_running=False, reuse=None, log_guard=False, stagger=False):
         import torch
         self.torch = torch
         self.m1 = _batched(model1)
@@ -100,6 +100,7 @@ class BatchSelfPlay(object):
         if self.reuse and self.m2 is not None:
             raise ValueError('tree reuse needs ONE model: the previous ply of a two-model game was searched with the other one (selfplay.py:30,59)')
         self.log_guard = bool(log_guard)
+        self.stagger = bool(stagger)
         self.steps = 0                                     # free-running: [net -> advance] steps taken
         if self.free_running:
             if self.reuse:
@@ -108,6 +109,8 @@ class BatchSelfPlay(object):
             self._p0 = torch.zeros((n_slots, NUM_ACTIONS), dtype=torch.float64, device=dev)     # the first call's answer to no request
             self._v0 = torch.zeros(n_slots, dtype=torch.float32, device=dev)
             self._started = False
+            self._round_no = 0
+            self.net_events = None                         # bench.py: [(start, end)] HIP events around the evaluator launch of the plain (uncaptured) steps
 
     def _evaluate(self, root_is_p2):
         p, v = self.m1.evaluate_batch(self.planes)
@@ -158,6 +161,9 @@ class BatchSelfPlay(object):
 
     # ---- free-running stepping ---------------------------------------------------------------------------------------------
     FREE_UNROLL = 25         # [net -> advance | boundary] rounds per captured hipGraph
+    BOUNDARY_EVERY = 2       # ccsp_boundary in every k-th round only (a slot between two searches then waits up to k - 1 rounds;
+                             # measured at 4096 x 400: k = 1 / 2 / 3 -> 17.06 / 17.37 / 17.43 M node-expansions/s)
+    DEBUG = False            # diagnostic tallies of ccsp_advance / ccsp_boundary in counters 12-14 (tools/bench_free.py --debug)
     SIDE_STREAM = False      # ccsp_boundary on a stream of its own beside the next evaluator launch (measured: hipGraphs with forks
                              # stop overlapping the two half-batches' graphs; kept for experiments)
 
@@ -176,15 +182,17 @@ class BatchSelfPlay(object):
         ply is long -- pi, sampling, rules, Dirichlet noise -- and runs beside the NEXT evaluator launch instead of in front of it)"""
         torch, e = self.torch, self.eng
         if not self.SIDE_STREAM:
-            e.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
-            e.boundary(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
+            e.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, debug=self.DEBUG)
+            self._round_no += 1
+            if self._round_no % self.BOUNDARY_EVERY == 0:
+                e.boundary(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, stagger=self.stagger, debug=self.DEBUG)
             return
         cur = torch.cuda.current_stream()
         cur.wait_stream(self._side)                        # the previous round's boundary work: done before this round's advance
-        e.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
+        e.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, debug=self.DEBUG)
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
-            e.boundary(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard)
+            e.boundary(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, stagger=self.stagger, debug=self.DEBUG)
         if not capturing:
             p.record_stream(self._side)
             v.record_stream(self._side)
@@ -231,7 +239,14 @@ class BatchSelfPlay(object):
                 self._graph.replay()
                 done += self._unroll
         while done < n:
-            p, v = self._evaluate_free()
+            if self.net_events is not None:                # the evaluator launch as it runs in the pipeline, timed on its own stream
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                p, v = self._evaluate_free()
+                ev1.record()
+                self.net_events.append((ev0, ev1))
+            else:
+                p, v = self._evaluate_free()
             self._round(p, v)
             done += 1
         torch.cuda.current_stream().wait_stream(self._side)
@@ -549,7 +564,7 @@ class SelfPlayRun(object):
         if free_running and hasattr(_batched(model1), 'model'):
             # slots run at their own pace (BatchSelfPlay): between two harvests a slot plays up to ~1.5 plies per `play_ply`; a slot that
             # could find the log full waits for the harvest (log_guard) instead of losing a row
-            kw.update(free_running=True, reuse=reuse, log_guard=True)
+            kw.update(free_running=True, reuse=reuse, log_guard=True, stagger=n_games > n_slots)      # (restarting slots: a long run)
             cap = n_slots * (2 * self.harvest_every + 2)
         self.free_running = bool(kw.get('free_running'))
         if n_parts > 1:

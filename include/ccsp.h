@@ -265,12 +265,16 @@ int ccsp_ply_end(ccsp_ctx *ctx, void *stream);
  *   CCSP_ADVANCE_LOG_GUARD  a slot whose finished ply might not find a free row in the sample log waits for the caller's next
  *                           ccsp_log_clear instead of ending its game in CCSP_ST_ERROR (for callers that harvest the log as they go).
  * model_sel (device, [n_slots], may be NULL): 1 where the request is to be answered by player two's model (selfplay.py:30,36,59).
- * Slots that ask for nothing in a round (game over, budget of evaluator-free simulations spent) ignore their row of the next answer. */
-enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2 };
+ * Slots that ask for nothing in a round (game over, budget of evaluator-free simulations spent) ignore their row of the next answer.
+ *   CCSP_ADVANCE_STAGGER    (ccsp_boundary) slot g starts its FIRST game hash(g) mod `sims` rounds late, so that the slots' plies end evenly
+ *                           spread over the rounds from the start instead of in waves (every round then carries the same mix of cheap
+ *                           and expensive tree work).  A game's record does not depend on when it is played.
+ */
+enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2, CCSP_ADVANCE_STAGGER = 4, CCSP_ADVANCE_DEBUG = 8 /* diagnostic tallies in counters 12-14 */ };
 int ccsp_enable_tree_reuse(ccsp_ctx *ctx);
 int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
 int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
-/* evaluator-free simulations (won leaves, reused positions) a slot may complete in ONE ccsp_advance (default 4: bounds the launch's
+/* evaluator-free simulations (won leaves, reused positions) a slot may complete in ONE ccsp_advance (default 3: bounds the launch's
  * length; results do not depend on it; at least 1: a slot must be able to get past a won leaf).  Returns the previous value; n < 1 only reads it. */
 int ccsp_debug_advance_budget(int n);
 

@@ -16,10 +16,15 @@ ap.add_argument('--sims', type=int, default=400)
 ap.add_argument('--lockstep', action='store_true')
 ap.add_argument('--no-reuse', action='store_true')
 ap.add_argument('--side', action='store_true')
+ap.add_argument('--debug', action='store_true')
+ap.add_argument('--boundary-every', type=int, default=1)
+ap.add_argument('--harvest', type=int, default=4)
 ap.add_argument('--unroll', type=int, default=25)
 a = ap.parse_args()
 os.environ['CCSP_STRICT'] = '1'
 sp.BatchSelfPlay.SIDE_STREAM = a.side
+sp.BatchSelfPlay.DEBUG = a.debug
+sp.BatchSelfPlay.BOUNDARY_EVERY = a.boundary_every
 sp.BatchSelfPlay.FREE_UNROLL = a.unroll
 m = ResidualCNN()
 m.load_weights('tests/golden/good_model.h5')
@@ -31,11 +36,12 @@ for kind, budget in cases:
         L.ccsp_debug_advance_budget(budget)
     sink = sp.TrainDataSink(); sink.discard = True
     run = sp.SelfPlayRun(m, n_games=a.games * 64, sims=a.sims, seed=20261003, max_slots=a.games, keep_records=False, sink=sink,
-                         free_running=(kind == 'free'), reuse=(False if a.no_reuse else None))
+                         free_running=(kind == 'free'), reuse=(False if a.no_reuse else None), harvest_every=a.harvest)
     for _ in range(a.spread):
         run.play_ply()
     run.drain()
     torch.cuda.synchronize()
+    raw0 = [sum(x) for x in zip(*[b.eng.raw_counters() for b in run.b.parts])] if a.debug else None
     c0 = run.counters(); t0 = time.time()
     for _ in range(a.plies):
         run.play_ply()
@@ -49,4 +55,8 @@ for kind, budget in cases:
                           hit_rate=d['cache_hits'] / max(d['expansions'], 1), terminal_share=d['terminal_sims'] / max(d['sims'], 1),
                           plies_per_slot_per_play_ply=d['mcts_plies'] / a.plies / a.games, useful_eval_share=(d['expansions'] - d['cache_hits']) / evals,
                           games_per_s=(d['games_won'] + d['games_discarded']) / dt, errors=c1['errors'])), flush=True)
+    if a.debug:
+        raw1 = [sum(x) for x in zip(*[b.eng.raw_counters() for b in run.b.parts])]
+        calls = a.plies * (a.sims + 1) * a.games
+        print(json.dumps(dict(requests_share=(raw1[12] - raw0[12]) / calls, log_guard_waits=(raw1[13] - raw0[13]), budget_idle_share=(raw1[14] - raw0[14]) / calls)), flush=True)
     run.close()

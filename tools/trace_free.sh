@@ -24,6 +24,10 @@ for k, v in d.items():
 t0, t1 = rows[0][0], rows[-1][1]
 busy_net = sum(e - s for s, e, k, q in rows if k == 'net')
 print('window %.1f ms; net busy %.1f %% (sum of net durations / window)' % ((t1 - t0) / 1e6, 100.0 * busy_net / (t1 - t0)))
+adv = [(e - s) / 1e3 for s, e, k, q in rows if k == 'adv']
+print('adv durations in launch order (us):', ' '.join('%.0f' % x for x in adv[3000:3200]))
+bnd = [(e - s) / 1e3 for s, e, k, q in rows if k == 'bnd']
+print('bnd durations in launch order (us):', ' '.join('%.0f' % x for x in bnd[3000:3200]))
 # a sample of the timeline
 for s, e, k, q in rows[2000:2040]: print('%8.1f %8.1f %s q=%s' % ((s - t0) / 1e3, (e - s) / 1e3, k, q))
 PY
