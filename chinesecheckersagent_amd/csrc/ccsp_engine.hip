@@ -1513,10 +1513,10 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     // STAGGERED START: every slot's first game would begin in the same call and -- plies taking similar numbers of calls -- the slots
     // would end their plies in waves for dozens of plies: calls in which most slots are at the cheap middle of a search alternate with
     // calls in which most are at its expensive start (the reused top of the tree: simulation after simulation without the
-    // evaluator).  Slot g therefore sits out hash(g) mod `stagger` calls first (bits 16-31 of word 15 count them down; bit 9 = set
+    // evaluator).  A slot therefore sits out hash(id of its first game) mod `stagger` calls first (bits 16-31 of word 15 count them down; bit 9 = set
     // up).  A game's record does not depend on when it is played.
     if (phase == 0 && stagger > 1 && !((w15 >> 9) & 1)) {
-        const uint32_t wait = ((uint32_t)g * 2654435761u >> 8) % (uint32_t)stagger;
+        const uint32_t wait = (uint32_t)(ccsp_mix64(uni64(P.slots[g].w[4])) % (uint64_t)stagger);     // by GAME id: the same under any sharding
         if (lane == 0) P.slots[g].w[15] = (w15 & ~0xFFFF0000ULL) | (1ULL << 9) | ((uint64_t)wait << 16);
         if (wait) return;
     } else if (phase == 0 && ((w15 >> 16) & 0xFFFF)) {
