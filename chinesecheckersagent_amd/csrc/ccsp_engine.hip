@@ -120,8 +120,34 @@ constexpr int RCP_N = 422;          // reciprocal table entries kept in LDS by t
                                     // the same union needs, so that the per-wave LDS stays at 6.9 KB and THREE tree-kernel workgroups
                                     // fit beside an evaluator workgroup (ccsp_net.hip)
 
+// The line tables of ccsp_rules.h as the engine's one-wave workgroups keep them in LDS: both senses of a hop in ONE byte (two 3-bit
+// landing positions, 7 = none) -- 1340 bytes instead of 2236.  With the evaluator's 137-KB workgroup on a CU every byte of a tree
+// workgroup decides how many of them fit beside it (advance_kernel: 2.2 KB = ten; 3.1 KB was seven).
+struct EngineLines {
+    uint8_t lp[CCSP_NCELL][4];          // [cell][axis] = line << 3 | position
+    uint8_t cell[CCSP_NLINES][8];       // [line][position]
+    uint8_t base[CCSP_NLINES + 5];      // off-board bits of each line's pattern
+    uint8_t hopp[128][7];               // [pattern][position]: low nibble = landing in sense -, high nibble = in sense +
+};
+static_assert(sizeof(EngineLines) % 4 == 0, "copied as dwords");
+static constexpr EngineLines make_engine_lines() {
+    const ccsp_line_tables t = ccsp_make_lines();
+    EngineLines e{};
+    for (int c = 0; c < CCSP_NCELL; c++) for (int a = 0; a < 4; a++) e.lp[c][a] = t.lp[c][a];
+    for (int l = 0; l < CCSP_NLINES; l++) for (int q = 0; q < 8; q++) e.cell[l][q] = t.cell[l][q];
+    for (int l = 0; l < CCSP_NLINES + 5; l++) e.base[l] = t.base[l];
+    for (int pat = 0; pat < 128; pat++) for (int q = 0; q < 7; q++) e.hopp[pat][q] = (uint8_t)(t.hop[pat][q][0] | (t.hop[pat][q][1] << 4));
+    return e;
+}
+static __device__ const EngineLines ENGINE_LINES_DEV = make_engine_lines();
+__device__ __forceinline__ void load_engine_lines(EngineLines *lds, int tid) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&ENGINE_LINES_DEV);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
+    for (int i = tid; i < (int)(sizeof(EngineLines) / 4); i += 64) dst[i] = src[i];
+}
+
 struct Lds {                      // per-wave scratch (one wave per workgroup)
-    ccsp_line_tables T;           // line tables (ccsp_rules.h), copied from device constant data
+    EngineLines T;                // line tables, copied from device constant data
     uint32_t lines[32];           // occupancy pattern of the 27 board lines for the position being expanded
     uint8_t lists[6][24];
     union {
@@ -130,7 +156,7 @@ struct Lds {                      // per-wave scratch (one wave per workgroup)
     };
     uint8_t cnt[8];
     // LAST: a kernel that neither ends plies nor draws root noise nor starts games nor divides through the table (advance_kernel)
-    // allocates the struct only up to here (LDS_LIGHT bytes) -- 3.0 KB instead of 6.4: seven of its workgroups fit beside an evaluator
+    // allocates the struct only up to here (LDS_LIGHT bytes) -- 2.2 KB instead of 5.6: ten of its workgroups fit beside an evaluator
     // workgroup, not three
     union {
         struct {                  // ply begin / end: pi vector, Dirichlet draws
@@ -235,7 +261,7 @@ __device__ __forceinline__ int wave_movegen_impl(Lds &lds, const ccsp_sr &st, in
     const int grp = lane >> 3, dir = lane & 7;
     const bool act = (grp < 6) & (dir < 6);
     const int g = grp < 6 ? grp : 0, d = dir < 6 ? dir : 0;
-    const ccsp_line_tables &T = lds.T;
+    const EngineLines &T = lds.T;
     __syncthreads();                                   // previous users of lists/cnt/lines are done
     // occupancy patterns of the 27 lines: off-board bits preset, then one bit per checker and axis
     if (lane < CCSP_NLINES) lds.lines[lane] = T.base[lane];
@@ -284,7 +310,7 @@ __device__ __forceinline__ int wave_movegen_impl(Lds &lds, const ccsp_sr &st, in
         const int pos = axis == 0 ? r : (axis == 1 ? c : (r < c ? r : c));
         uint32_t pat = lds.lines[line];
         pat = line == oline ? (pat & omask) : pat;
-        const int hp = T.hop[pat][pos][sense];
+        const int hp = (T.hopp[pat][pos] >> (4 * sense)) & 7;
         const int land = x + (hp - pos) * stride;                       // = T.cell[line][hp] when hp < 7
         const bool ok = act & fresh & (hp < 7) & (((visited >> (land & 63)) & 1) == 0);
         const uint32_t m = (uint32_t)(__ballot(ok) >> (8 * grp)) & 0x3Fu;
@@ -1192,7 +1218,7 @@ __global__ __launch_bounds__(64) void fused_begin_kernel(Params P, int evaluator
     const int g = blockIdx.x;
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
-    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
+    load_engine_lines(&lds.T, lane_id());
     __syncthreads();
     fused_begin_core(P, lds, g, sl, evaluator);
 }
@@ -1271,7 +1297,7 @@ __global__ __launch_bounds__(64, 4) void fused_sims_kernel(Params P, int evaluat
     __shared__ Lds lds;
     const int g = blockIdx.x;
     if (uni64(P.slots[g].w[14]) != 1) return;
-    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
+    load_engine_lines(&lds.T, lane_id());
     __syncthreads();
     fused_sims_core(P, lds, g, evaluator);
 }
@@ -1293,7 +1319,7 @@ __global__ __launch_bounds__(64) void fused_end_kernel(Params P) {
     const int g = blockIdx.x;
     if (uni64(P.slots[g].w[14]) != 1) return;
     Slot sl = load_slot(P.slots + g);
-    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);        // (the opening plies of a restarted game generate moves)
+    load_engine_lines(&lds.T, lane_id());        // (the opening plies of a restarted game generate moves)
     __syncthreads();
     fused_end_core(P, lds, g, sl);
 }
@@ -1303,7 +1329,7 @@ __global__ __launch_bounds__(64) void fused_end_kernel(Params P) {
 __global__ __launch_bounds__(64, 4) void fused_plies_kernel(Params P, int evaluator, int n_plies) {
     __shared__ Lds lds;
     const int g = blockIdx.x;
-    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
+    load_engine_lines(&lds.T, lane_id());
     __syncthreads();
     for (int i = 0; i < n_plies; i++) {
         Slot sl = load_slot(P.slots + g);
@@ -1334,7 +1360,7 @@ __global__ __launch_bounds__(64) void root_expand_kernel(Params P, const double 
     const int g = blockIdx.x;
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING || no_search(P, sl)) return;
-    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
+    load_engine_lines(&lds.T, lane_id());
     __syncthreads();
     uint8_t *pool = P.pool + (uint64_t)g * P.pool_stride;
     Tally tl; tally_zero(tl);
@@ -1401,7 +1427,7 @@ __device__ __forceinline__ void expand_backup_core(const Params &P, Lds &lds, in
     const uint64_t *path = P.path + (uint64_t)g * P.path_stride;
     float val = 0.0f;
     if (pd.kind == 1) {
-        ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
+        load_engine_lines(&lds.T, lane_id());
         __syncthreads();
         EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = v[g]; ev.p_edges = nullptr; ev.shadow = 0;
         val = ev.v_ext;
@@ -1526,7 +1552,7 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
     __builtin_amdgcn_s_setprio(2);
-    ccsp_load_lines_to_lds(&lds.T, lane, 64);
+    load_engine_lines(&lds.T, lane);
     __syncthreads();
     const bool reuse = (flags & CCSP_ADVANCE_REUSE) != 0;
     uint32_t *acc = P.stepacc + (size_t)g * 8;
@@ -1608,7 +1634,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
     __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch: the short tree kernels go first
-    ccsp_load_lines_to_lds(&lds.T, lane, 64);
+    load_engine_lines(&lds.T, lane);
     __syncthreads();
     const bool reuse = (flags & CCSP_ADVANCE_REUSE) != 0;
     uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
@@ -1709,7 +1735,7 @@ __global__ __launch_bounds__(64) void ply_end_kernel(Params P) {
     const int g = blockIdx.x;
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
-    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
+    load_engine_lines(&lds.T, lane_id());
     __syncthreads();
     uint8_t *pool = P.pool + (uint64_t)g * P.pool_stride;
     Tally tl; tally_zero(tl);
@@ -1735,7 +1761,7 @@ __global__ __launch_bounds__(64) void greedy_plies_kernel(Params P, int n_plies)
     const int g = blockIdx.x;
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
-    ccsp_load_lines_to_lds(&lds.T, lane_id(), 64);
+    load_engine_lines(&lds.T, lane_id());
     __syncthreads();
     Tally tl; tally_zero(tl);
     for (int i = 0; i < n_plies && sl.status == CCSP_ST_RUNNING; i++) {

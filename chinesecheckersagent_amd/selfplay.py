@@ -53,6 +53,28 @@ def _batched(model):
     return model if hasattr(model, 'evaluate_batch') else _PredictAdapter(model)
 
 
+_malloc_tuned = [False]
+
+
+def tune_host_allocator():
+    """glibc serves every large array from a fresh mmap and gives it back on free: the harvest's copies, the float64 planes and the
+    gathered pi rows of every conversion are then first-touch page faults -- measured 11 us per 2.7-KB row against 0.3 us once the heap
+    keeps its pages (mmap threshold 1 GB, no trimming).  Called once by SelfPlayRun (the rank processes of the N-GPU generator spend a
+    host core per GPU on conversion otherwise); CCSP_NO_MALLOPT=1 leaves the process's allocator alone."""
+    import os
+    if _malloc_tuned[0] or os.environ.get('CCSP_NO_MALLOPT') == '1':
+        return
+    _malloc_tuned[0] = True
+    try:
+        import ctypes
+        libc = ctypes.CDLL('libc.so.6')
+        libc.mallopt(-3, 1 << 30)              # M_MMAP_THRESHOLD
+        libc.mallopt(-1, (1 << 31) - 1)        # M_TRIM_THRESHOLD
+        libc.mallopt(-2, 1 << 28)              # M_TOP_PAD
+    except Exception:                          # not glibc: nothing to tune
+        pass
+
+
 def _strict():
     """CCSP_STRICT=1 (bench.py sets it): a performance path that cannot be taken is an error, not a silent fallback"""
     import os
@@ -552,6 +574,7 @@ class SelfPlayRun(object):
     def __init__(self, model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False, first_game=0,
                  game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY, use_graph=True, keep_records=True,
                  sink=None, n_parts=None, free_running=True, reuse=None):
+        tune_host_allocator()
         n_games = int(n_games)
         n_slots = max(1, min(n_games, int(max_slots)))
         if n_parts is None:
@@ -682,24 +705,27 @@ class TrainDataSink(object):
     file (utils.save_train_data's datasets board_x / pi_y / v_y, chunked along the first axis: h5lite.StreamWriter) while the run
     goes on -- host memory stays bounded, the file is whole when close() returns."""
 
-    def __init__(self, path=None, chunk_rows=4096):
+    def __init__(self, path=None, chunk_rows=4096, with_games=False):
         self.chunks = []
         self.rows = 0
         self.discard = False              # rows arriving are dropped (bench.py: games that ended before the timed region)
         self.writer = None
+        self.with_games = bool(with_games)       # a fourth dataset `game`: the id of every row's game (the N-GPU generator merges by it)
         if path is not None:
             self.open(path, chunk_rows)
 
     def open(self, path, chunk_rows=4096):
         from .h5lite import StreamWriter
-        self.writer = StreamWriter(path, [('board_x', (7, 7, 7), '<f8'), ('pi_y', (NUM_ACTIONS,), '<f8'), ('v_y', (), '<i8')],
-                                   chunk_rows=chunk_rows)
+        specs = [('board_x', (7, 7, 7), '<f8'), ('pi_y', (NUM_ACTIONS,), '<f8'), ('v_y', (), '<i8')]
+        if self.with_games:
+            specs.append(('game', (), '<i8'))
+        self.writer = StreamWriter(path, specs, chunk_rows=chunk_rows)
 
     def __call__(self, board_x, pi_y, v_y, games):
         if self.discard:
             return
         if self.writer is not None:
-            self.writer.append([board_x, pi_y, v_y])
+            self.writer.append([board_x, pi_y, v_y] + ([np.asarray(games, dtype=np.int64)] if self.with_games else []))
         else:
             self.chunks.append((board_x, pi_y, v_y, games))
         self.rows += len(v_y)
@@ -836,6 +862,8 @@ def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model
             argv += ['--model2', model2_path]
         if randomised:
             argv += ['--randomised']
+        if as_arrays:
+            argv += ['--arrays']                          # the ranks stream (board_x, pi_y, v_y, game) into files: their memory stays bounded
         extra = {'PYTHONPATH': os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
                                                ([os.environ['PYTHONPATH']] if os.environ.get('PYTHONPATH') else []))}
         if devices is not None and len(set(devices)) < len(devices):
@@ -843,6 +871,24 @@ def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model
         rc = launch.run_ranks(argv, num_workers, devices=devices, extra_env=extra, timeout=timeout)
         if rc:
             raise _lib.CcspError('generate_self_play_in_parallel: %s' % ('timed out after %s s' % timeout if rc == 124 else 'a rank process failed (exit code %d)' % rc))
+        if as_arrays:
+            from .h5lite import H5File
+            parts = []
+            for r in range(num_workers):
+                path = os.path.join(out_dir, 'selfplay-rank%d.h5' % r)
+                if os.path.exists(path):
+                    f = H5File(path)
+                    parts.append(tuple(f.get(k) for k in ('board_x', 'pi_y', 'v_y', 'game')))
+            if parts:
+                bx, py, vy, gid = (np.concatenate([x[i] for x in parts]) for i in range(4))
+                o = np.argsort(gid, kind='stable')          # games by id; a game's rows stay in ply order
+                out = (bx[o], py[o], vy[o])
+            else:
+                out = (np.zeros((0, 7, 7, 7)), np.zeros((0, NUM_ACTIONS)), np.zeros(0, dtype=np.int64))
+            if return_summary:
+                with open(os.path.join(out_dir, 'summary.json')) as f:
+                    return out, json.load(f)
+            return out
         results = np.zeros(num_self_play, dtype=_lib.RESULT_DTYPE)
         results['status'] = 0xFF
         rows = []
@@ -856,11 +902,8 @@ def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model
             rows.append((z['state'], z['meta'], z['pi']))
         st, meta, pi = (np.concatenate([x[i] for x in rows]) for i in range(3)) if rows else \
             (np.zeros(0, dtype=_lib.STATE_DTYPE), np.zeros(0, dtype=_lib.META_DTYPE), np.zeros((0, NUM_ACTIONS)))
-        if as_arrays:
-            out = utils.log_to_train_data(st, meta, pi, results, first_game=first_game, game_stride=1, randomised=randomised)
-        else:
-            games = _games_from_rows(st, meta, pi, results, first_game, 1, randomised)
-            out = [(h, r) for h, r in games if h is not None and r is not None and not isinstance(h, str)]
+        games = _games_from_rows(st, meta, pi, results, first_game, 1, randomised)       # the object path: one Python object per position
+        out = [(h, r) for h, r in games if h is not None and r is not None and not isinstance(h, str)]
         if return_summary:
             with open(os.path.join(out_dir, 'summary.json')) as f:
                 return out, json.load(f)

@@ -74,39 +74,53 @@ def states_to_model_input(states, players):
     """to_model_input for MANY 32-byte records at once (numpy, no Python loop over positions):
     states = structured array with 'pos' [2][6] and 'last' [4] (ccsp_state), players = player to move per record.
     -> float64 [N, 7, 7, 7], the same values as to_model_input(BoardView(record), player) row by row.
-    (Built as bytes -- the planes hold 0 .. 6 -- and widened to float64 in one pass at the end.)"""
+    Built by SCATTERING the twelve checker ids of each of the six board planes straight into the zeroed float64 result (6 x 6 + 1
+    stores per position instead of several passes over 343 values: the conversion of a GPU's sample rows runs beside the GPU on a
+    fraction of a host core).  Undoing a move on a layer (utils.py:135-155) swaps two cells: on the list of checker positions that
+    is "a checker on one of the two cells stands on the other"."""
     states = np.asarray(states)
     n = len(states)
     pos = np.asarray(states['pos'], dtype=np.int64).reshape(n, 12)
     last = np.asarray(states['last'], dtype=np.int64).reshape(n, 4)
     pl = np.asarray(players, dtype=np.int64).reshape(n)
-    rows = np.arange(n)[:, None]
-    ids = np.arange(1, NUM_CHECKERS + 1, dtype=np.uint8)[None, :]
+    nc = BOARD_WIDTH * BOARD_HEIGHT
+    nch = BOARD_HIST_MOVES * 2 + 1
+    out = np.zeros((n, nc, nch), dtype=np.float64)
+    if n == 0:
+        return out.reshape(n, BOARD_WIDTH, BOARD_HEIGHT, nch)
+    flat = out.reshape(-1)
+    ids = np.arange(1, NUM_CHECKERS + 1, dtype=np.float64)[None, :]
     one = (pl == PLAYER_ONE)[:, None]
     mine = np.where(one, pos[:, :6], pos[:, 6:])
     theirs = np.where(one, pos[:, 6:], pos[:, :6])
-    nc = BOARD_WIDTH * BOARD_HEIGHT
-    cur = np.zeros((n, nc), dtype=np.uint8)
-    op = np.zeros((n, nc), dtype=np.uint8)
-    cur[rows, mine] = ids
-    op[rows, theirs] = ids
+    base = (np.arange(n, dtype=np.int64) * (nc * nch))[:, None]
+
+    def put(rows, cells, ch):
+        """plane `ch` of the positions `rows` (None = all): id i + 1 on the cell of checker i"""
+        if rows is None:
+            flat[(base + cells * nch + ch).reshape(-1)] = np.broadcast_to(ids, cells.shape).reshape(-1)
+        elif len(rows):
+            flat[(base[rows] + cells[rows] * nch + ch).reshape(-1)] = np.broadcast_to(ids, (len(rows), NUM_CHECKERS)).reshape(-1)
+
+    def swapped(cells, f, t):
+        f, t = f[:, None], t[:, None]
+        return np.where(cells == f, t, np.where(cells == t, f, cells))
+    put(None, mine, 0)
+    put(None, theirs, 1)
     # one ply back: the opponent's last move undone on the opponent's layer (utils.py:135-155); NO_MOVE ends the history
     m1 = last[:, 0] != NO_MOVE
     r1 = np.nonzero(m1)[0]
-    op1 = op.copy()
-    f, t = last[r1, 0], last[r1, 1]
-    op1[r1, f], op1[r1, t] = op[r1, t], op[r1, f]
+    theirs1 = swapped(theirs, last[:, 0], last[:, 1])
+    put(r1, mine, 2)
+    put(r1, theirs1, 3)
     # two plies back: the mover's own previous move undone on its layer
     m2 = m1 & (last[:, 2] != NO_MOVE)
     r2 = np.nonzero(m2)[0]
-    cur2 = cur.copy()
-    f, t = last[r2, 2], last[r2, 3]
-    cur2[r2, f], cur2[r2, t] = cur[r2, t], cur[r2, f]
-    z = np.zeros((n, nc), dtype=np.uint8)
-    m1c, m2c = m1[:, None], m2[:, None]
-    planes = np.stack([cur, op, np.where(m1c, cur, z), np.where(m1c, op1, z), np.where(m2c, cur2, z), np.where(m2c, op1, z),
-                       np.broadcast_to((pl == PLAYER_TWO).astype(np.uint8)[:, None], (n, nc))], axis=2)
-    return planes.astype(np.float64).reshape(n, BOARD_WIDTH, BOARD_HEIGHT, BOARD_HIST_MOVES * 2 + 1)
+    mine2 = swapped(mine, last[:, 2], last[:, 3])
+    put(r2, mine2, 4)
+    put(r2, theirs1, 5)
+    out[pl == PLAYER_TWO, :, nch - 1] = 1.0
+    return out.reshape(n, BOARD_WIDTH, BOARD_HEIGHT, nch)
 
 
 def log_to_train_data(states, meta, pi, results, first_game=0, game_stride=1, randomised=False, return_games=False):

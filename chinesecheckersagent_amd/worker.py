@@ -29,9 +29,17 @@ def selfplay_rank(a):
     out = dict(rank=rank, world=world, games=n_mine)
     hist = np.zeros(_lib.NUM_ACTIONS, dtype=np.uint64)
     counters = {}
+    import resource
+    import time
+    t0 = time.time()
     if n_mine > 0:
+        # --arrays: the finished games' rows are converted and STREAMED into this rank's file while the GPU plays on (host memory
+        # bounded by a chunk, whatever the number of games); without it the rows are kept for the parent's object path (play
+        # histories as Python objects: for small counts)
+        sink = sp.TrainDataSink(path=os.path.join(a.out, 'selfplay-rank%d.h5' % rank), with_games=True) if a.arrays else None
         run = sp.SelfPlayRun(model, model2, n_games=n_mine, sims=a.sims, seed=a.seed, randomised=a.randomised,
-                             first_game=a.first_game + rank, game_stride=world, device=local, max_slots=a.max_slots)
+                             first_game=a.first_game + rank, game_stride=world, device=local, max_slots=a.max_slots,
+                             keep_records=not a.arrays, sink=sink)
         try:
             run.run()
             counters = run.counters()
@@ -39,16 +47,27 @@ def selfplay_rank(a):
             for b in parts:
                 hist += b.eng.visit_histogram()
             store = run.store
-            store.take_finished()
-            rows = list(store._records)
-            if rows:
-                st, meta, pi = (np.concatenate([x[i] for x in rows]) for i in range(3))
+            if a.arrays:
+                out['rows'] = int(sink.rows)
+                sink.close()
             else:
-                st, meta, pi = np.zeros(0, dtype=_lib.STATE_DTYPE), np.zeros(0, dtype=_lib.META_DTYPE), np.zeros((0, _lib.NUM_ACTIONS))
-            np.savez(os.path.join(a.out, 'selfplay-rank%d.npz' % rank), state=st, meta=meta, pi=pi, results=store.results,
-                     first_game=a.first_game + rank, game_stride=world)
+                store.take_finished()
+                rows = list(store._records)
+                if rows:
+                    st, meta, pi = (np.concatenate([x[i] for x in rows]) for i in range(3))
+                else:
+                    st, meta, pi = np.zeros(0, dtype=_lib.STATE_DTYPE), np.zeros(0, dtype=_lib.META_DTYPE), np.zeros((0, _lib.NUM_ACTIONS))
+                np.savez(os.path.join(a.out, 'selfplay-rank%d.npz' % rank), state=st, meta=meta, pi=pi, results=store.results,
+                         first_game=a.first_game + rank, game_stride=world)
         finally:
+            if sink is not None and sink.writer is not None:
+                sink.writer.abort()
             run.close()
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    host = dict(rank=rank, wall_s=time.time() - t0, host_cpu_s=ru.ru_utime + ru.ru_stime, peak_rss_mb=ru.ru_maxrss / 1024.0,
+                rows=out.get('rows'), games=n_mine)
+    with open(os.path.join(a.out, 'host-rank%d.json' % rank), 'w') as f:          # (what the N = 8 host-load rehearsal reads)
+        json.dump(host, f)
     tot, hist_all = counters, hist
     if dist is not None:
         tot, hist_all = summary.allreduce_summary(counters, hist, dist, device=coll_device(dist))
@@ -75,6 +94,7 @@ def main(argv=None):
     s.add_argument('--first-game', type=int, default=0)
     s.add_argument('--max-slots', type=int, default=4096)
     s.add_argument('--randomised', action='store_true')
+    s.add_argument('--arrays', action='store_true', help='stream (board_x, pi_y, v_y, game) into DIR/selfplay-rank{r}.h5 instead of keeping the rows')
     s.add_argument('--out', required=True)
     e = sub.add_parser('evolve')
     e.add_argument('--config', required=True, help='JSON file with the arguments of train.evolve')

@@ -46,5 +46,13 @@ if what in ('all', 'fused'):
         e.play_plies(_lib.EVAL_UNIFORM, 4)      # fused_plies_kernel, four searched plies per launch
     torch.cuda.synchronize()
     e.close()
+if what in ('all', 'free'):         # the free-running stepped path on PLAIN launches (no hipGraph under --pmc): net_forward_kernel beside
+    m = ResidualCNN(); m.load_weights('tests/golden/good_model.h5')     # advance_kernel / boundary_kernel at 4096 slots x 400 simulations
+    run = sp.SelfPlayRun(m, n_games=4096 * 8, sims=400, seed=bench.SEED, max_slots=4096, keep_records=False, use_graph=False)
+    for b in (run.b.parts if hasattr(run.b, 'parts') else [run.b]):
+        b.play_steps(700)                        # one and a half plies of every slot: reused positions, ply ends and roots included
+    torch.cuda.synchronize()
+    print('free-running: counters', run.counters())
+    run.close()
 if what == 'stepped':            # hipGraph replays: NOT under --pmc (the counter passes never finished with it)
     print(sp.bench_net_plies(4096, 400, plies=1))

@@ -8,7 +8,8 @@ mkdir -p gpurun_out
 sets=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES"
       "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS"
       "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"
-      "TCC_HIT_sum TCC_MISS_sum")
+      "TCC_HIT_sum TCC_MISS_sum"
+      "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU")      # lane utilisation: thread-cycles / (instruction-cycles x 64)
 i=0
 for set in "${sets[@]}"; do
   i=$((i+1)); d=/tmp/pmc_${tag}_$i; rm -rf $d
@@ -48,3 +49,6 @@ json.dump(out, open('gpurun_out/%s_pmc.json' % tag, 'w'), indent=1)
 for k, o in out.items():
     print(k, {c: ('%.4g' % v) for c, v in o.items() if isinstance(v, float)})
 PY
+# the aggregate the profiles/ files are made from (largest-grid launches only), then the raw per-pass rows go: they exceed what gpurun copies back
+python3 tools/pmc_aggregate.py "$tag" gpurun_out/${tag}_pmc_agg.json > gpurun_out/${tag}_pmc_agg.txt 2>&1
+rm -f gpurun_out/${tag}_pmc_pass*.csv
