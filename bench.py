@@ -431,6 +431,7 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    _lib.prefer_blocking_sync(0 if os.environ.get('CCSP_BENCH_ONE_DEVICE') == '1' else local)      # a rank's waits sleep instead of spinning (a host core per rank: DESIGN.md section 8)
     _lib.require_gpu()                      # no CPU fallback: fail loudly
     # functional test hook for 1-GPU boxes: CCSP_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo for
     # the summary (RCCL refuses two ranks on one device).  Never set by the driver.

@@ -115,6 +115,29 @@ def lib():
     return _lib
 
 
+_blocking_sync = [None]
+
+
+def prefer_blocking_sync(device=None):
+    """hipSetDeviceFlags(hipDeviceScheduleBlockingSync): a host thread that waits for the GPU (the harvest's synchronisation, a rank of
+    the N-GPU generator between two graph launches) SLEEPS instead of spinning.  Measured on the GPU box (tools/host_spin_probe.py): a
+    rank of the generator keeps 2.0 host cores busy by default -- one of them this spin -- and 1.0 with the flag, at the same
+    throughput; eight ranks on a 16-core quota leave the converter threads no core otherwise.  Best called before the process
+    touches the GPU (launch.init_rank and bench.py do); later calls may be refused by the runtime, which is harmless.
+    CCSP_NO_BLOCKING_SYNC=1 leaves the runtime's default.  -> the runtime's return code, or None if not attempted."""
+    if _blocking_sync[0] is not None or os.environ.get('CCSP_NO_BLOCKING_SYNC') == '1':
+        return _blocking_sync[0]
+    try:
+        import torch
+        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))   # the runtime torch has loaded: the process's only one
+        if device is not None:
+            hip.hipSetDevice(int(device))                       # the flags are the current device's
+        _blocking_sync[0] = int(hip.hipSetDeviceFlags(4))
+    except Exception:
+        _blocking_sync[0] = -1
+    return _blocking_sync[0]
+
+
 def check(rc, what=''):
     if rc != OK:
         names = {EINVAL: 'EINVAL', ENOMEM: 'ENOMEM', EHIP: 'EHIP', ENODEVICE: 'ENODEVICE', ESTATE: 'ESTATE'}

@@ -80,6 +80,8 @@ def init_rank(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    from ._lib import prefer_blocking_sync
+    prefer_blocking_sync(local)                           # before the first GPU call of the rank: waits sleep instead of spinning
     torch.cuda.set_device(local)
     dist = None
     if world > 1:

@@ -575,6 +575,7 @@ class SelfPlayRun(object):
                  game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY, use_graph=True, keep_records=True,
                  sink=None, n_parts=None, free_running=True, reuse=None):
         tune_host_allocator()
+        _lib.prefer_blocking_sync()                        # (effective when the process has not touched the GPU yet)
         n_games = int(n_games)
         n_slots = max(1, min(n_games, int(max_slots)))
         if n_parts is None:

@@ -51,7 +51,18 @@ for k, x in list(d.items()):
                                        wait_inst_lds_quad=x['SQ_WAIT_INST_LDS'], wave_cycles_quad=x['SQ_WAVE_CYCLES'],
                                        wait_any_quad=x['SQ_WAIT_ANY'], wait_inst_any_quad=x['SQ_WAIT_INST_ANY'],
                                        launch_ms_under_pmc=x['launch_us_under_pmc']['SQ_VALU_MFMA_BUSY_CYCLES'] / 1e3, vgpr=x['vgpr'], source=src)
+    elif k in ('advance_kernel', 'boundary_kernel'):
+        # the free-running stepped path on plain launches (tools/kernels_once.py `free`): per launch of 2048 slots (one half-batch)
+        c[k] = dict(slots=x['grid_threads'] // 64, fetch_size_kb=x['FETCH_SIZE'], write_size_kb=x['WRITE_SIZE'],
+                    hbm_bytes_per_launch=(2 * x['FETCH_SIZE'] + x['WRITE_SIZE']) * 1024.0,
+                    insts_valu=x['SQ_INSTS_VALU'], insts_salu=x['SQ_INSTS_SALU'], insts_lds=x['SQ_INSTS_LDS'],
+                    insts_vmem_rd=x['SQ_INSTS_VMEM_RD'], insts_vmem_wr=x['SQ_INSTS_VMEM_WR'],
+                    lanes_per_valu_inst=x['SQ_THREAD_CYCLES_VALU'] / x['SQ_ACTIVE_INST_VALU'],
+                    wave_cycles_quad=x['SQ_WAVE_CYCLES'], wait_any_quad=x['SQ_WAIT_ANY'], tcc_hit=x['TCC_HIT_sum'], tcc_miss=x['TCC_MISS_sum'],
+                    launch_us_under_pmc=x['launch_us_under_pmc']['SQ_INSTS_VALU'], vgpr=x['vgpr'], lds_bytes=x['lds_bytes'], source=src)
     else:
         continue
+    if 'SQ_THREAD_CYCLES_VALU' in x and k in c and 'lanes_per_valu_inst' not in c[k]:
+        c[k]['lanes_per_valu_inst'] = x['SQ_THREAD_CYCLES_VALU'] / x['SQ_ACTIVE_INST_VALU']      # active lanes per VALU instruction-cycle, of 64
     print('updated', k)
 json.dump(c, open(path, 'w'), indent=1)
