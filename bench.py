@@ -293,7 +293,8 @@ def config3(args, torch, rank, world, local, barrier):
         dt = time.time() - t0
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         c1 = run.counters()
-        net_in_pipeline_ms = [a.elapsed_time(b) for b_ in parts_ for a, b in (getattr(b_, 'net_events', None) or [])]
+        net_in_pipeline_ms = [ev[0].elapsed_time(ev[1]) for b_ in parts_ for ev in (getattr(b_, 'net_events', None) or [])]
+        tree_in_pipeline_ms = [ev[1].elapsed_time(ev[2]) for b_ in parts_ for ev in (getattr(b_, 'net_events', None) or [])]
         size = os.path.getsize(path)
         parts = len(run.b.parts) if hasattr(run.b, 'parts') else 1
         graphs = [b._graph is not None for b in (run.b.parts if hasattr(run.b, 'parts') else [run.b])]
@@ -310,6 +311,7 @@ def config3(args, torch, rank, world, local, barrier):
                        n_slots=run.n_slots, free_running=bool(getattr(run, 'free_running', False)),
                        net_in_pipeline_ms=(sorted(net_in_pipeline_ms)[len(net_in_pipeline_ms) // 2] if net_in_pipeline_ms else None),
                        net_in_pipeline_samples=len(net_in_pipeline_ms),
+                       tree_in_pipeline_ms=(sorted(tree_in_pipeline_ms)[len(tree_in_pipeline_ms) // 2] if tree_in_pipeline_ms else None),
                        host_cpu_s=(ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime), peak_rss_mb=ru1.ru_maxrss / 1024.0)
 
 
@@ -566,6 +568,7 @@ def main():
                                 'wall time of the timed plies / evaluator launches in them (no uncaptured step to put events around)',
                          'launches_in_timed_region_per_gpu': launches,
                          'achieved_isolated': tf, 'frac_isolated': tf / MFMA_F32_PEAK_TFLOPS, 'avg_launch_ms_isolated': k_ms,
+                         'tree_kernels_ms_in_the_same_rounds': info.get('tree_in_pipeline_ms'),      # advance (+ boundary) of the timed round, same events
                          'wall_ms_per_launch': max(h[2] for h in host) / launches * 1e3,
                          'wall_frac': info['n_pos'] * NET_FLOP_PER_EVAL / (max(h[2] for h in host) / launches) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          })(max_over_ranks_in(info)),

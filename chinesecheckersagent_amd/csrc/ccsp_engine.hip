@@ -99,6 +99,7 @@ struct Params {
     const double *pow_tab;
     const double *rcp_tab;        // 1/i, max(sims + 2, RCP_N) entries
     unsigned long long *counters;
+    unsigned long long *dbg;      // [64] diagnostic cycle sums of advance_kernel (CCSP_ADVANCE_DEBUG; ccsp_debug_read)
     uint32_t *stepacc;            // [n_slots][8] per-slot tallies of the stepped path (flushed once per ply: no
                                   // global atomics inside the per-simulation kernels)
     unsigned long long *visit_hist;
@@ -1633,7 +1634,10 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
     if (phase != 1) return;                               // at a ply boundary: boundary_kernel's business
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
-    __builtin_amdgcn_s_setprio(2);       // beside an evaluator launch: the short tree kernels go first
+#ifndef CCSP_ADVANCE_PRIO
+#define CCSP_ADVANCE_PRIO 2
+#endif
+    __builtin_amdgcn_s_setprio(CCSP_ADVANCE_PRIO);       // beside an evaluator launch: the short tree kernels go first
     load_engine_lines(&lds.T, lane);
     __syncthreads();
     const bool reuse = (flags & CCSP_ADVANCE_REUSE) != 0;
@@ -1652,6 +1656,15 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
     bool answered = pd.kind == 1;                         // the evaluator's answer for the leaf this slot asked about last time
     uint32_t request = 0;
     int spent = 0;
+    // diagnostic (CCSP_ADVANCE_DEBUG): cycles of this wave per phase -- [0] set-up, [1] expansion, [2] backup, [3] selection + shadow,
+    // [4] encode + hand-off, [5] whole call, [6] calls, [7] expansions, [8] selections -- summed over the waves into P.dbg
+    const bool dbg = (flags & CCSP_ADVANCE_DEBUG) != 0;
+    unsigned long long t_exp = 0, t_bak = 0, t_sel = 0, t_enc = 0, n_exp = 0, n_sel = 0, tq = 0;
+    const unsigned long long t_begin = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long t_mark = t_begin;
+#define ADV_LAP(acc) do { if (dbg) { __builtin_amdgcn_s_waitcnt(0); tq = __builtin_amdgcn_s_memtime(); acc += tq - t_mark; t_mark = tq; } } while (0)
+    unsigned long long t_setup = 0;
+    ADV_LAP(t_setup);
     for (;;) {
         ccsp_sr leaf; int leaf_player, depth; uint32_t link_off;
         uint64_t mypath = 0; double myW = 0.0; uint32_t myN = 0;
@@ -1672,6 +1685,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
             a_sims += 1; a_depth += (uint32_t)lf.depth; a_edges += edges;
             leaf = lf.st; leaf_player = lf.player; depth = lf.depth; link_off = lf.link_off;
             have_stats = true;
+            n_sel += 1;
             if (lf.kind == 2) {                           // a won leaf: backed up at once (MCTS.py:81-90)
                 if (last) { a_sims -= 1; a_depth -= (uint32_t)lf.depth; a_edges -= edges; break; }   // (selected again in the next call)
                 terminal = true; a_term += 1;
@@ -1689,8 +1703,10 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
                         q[1] = make_ulonglong2(leaf.a, leaf.b);
                         q[2] = make_ulonglong2(1ULL | ((uint64_t)(uint32_t)depth << 32), (uint64_t)link_off | ((uint64_t)(uint32_t)leaf_player << 32));
                     }
+                    ADV_LAP(t_sel);
                     wave_encode(lds, leaf, leaf_player, planes + (uint64_t)g * CCSP_PLANES);
                     request = 1;
+                    ADV_LAP(t_enc);
                     break;
                 }
                 if (last) { a_sims -= 1; a_depth -= (uint32_t)lf.depth; a_edges -= edges; break; }   // (no request: this slot's row of the next evaluator launch is idle)
@@ -1699,6 +1715,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
                 a_hits += 1;
             }
             spent += 1;
+            ADV_LAP(t_sel);
         }
         if (!terminal) {
             SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
@@ -1709,10 +1726,20 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
             if (k > 0 && lane == 0) *reinterpret_cast<uint32_t *>(pool + link_off) = ((noff >> 3) << 7) | (uint32_t)k;
             a_exp += 1; a_children += (uint32_t)k; sl.expansions += 1;
             __syncthreads();
+            n_exp += 1;
+            ADV_LAP(t_exp);
         }
         wave_backup(pool, path, mypath, myW, myN, have_stats, depth, terminal, ev.v_ext);
         sl.sim += 1;
         __syncthreads();                                  // this simulation's stores before the next one's loads
+        ADV_LAP(t_bak);
+    }
+    if (dbg && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        atomicAdd(&P.dbg[0], t_setup); atomicAdd(&P.dbg[1], t_exp); atomicAdd(&P.dbg[2], t_bak); atomicAdd(&P.dbg[3], t_sel);
+        atomicAdd(&P.dbg[4], t_enc); atomicAdd(&P.dbg[5], t_end - t_begin); atomicAdd(&P.dbg[6], 1ULL); atomicAdd(&P.dbg[7], n_exp);
+        atomicAdd(&P.dbg[8], n_sel); atomicMax(&P.dbg[9], t_end - t_begin);
     }
     if (lane == 0) {
         if (request != 1) P.pend[g].kind = 0;             // nothing asked: the search is done, or the budget is spent
@@ -1841,7 +1868,7 @@ int ccsp_destroy(ccsp_ctx *ctx) {
     if (!ctx) return CCSP_OK;
     ctx_scope scope_(ctx, nullptr);
     Params &P = ctx->P;
-    void *ptrs[] = {P.slots, P.pend, P.pool, P.pool2, P.path, ctx->sqrt_tab, ctx->pow_tab, ctx->rcp_tab, P.counters, P.stepacc, P.visit_hist,
+    void *ptrs[] = {P.slots, P.pend, P.pool, P.pool2, P.dbg, P.path, ctx->sqrt_tab, ctx->pow_tab, ctx->rcp_tab, P.counters, P.stepacc, P.visit_hist,
                     P.log_state, P.log_meta, P.log_pi, P.log_count, P.results};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete ctx;
@@ -1897,6 +1924,8 @@ static ccsp_ctx *create_on_device(const ccsp_config *cfg, int *err) {
     CTXALLOC(&P.pool, ctx->pool_bytes);
     CTXALLOC(&P.path, ctx->path_bytes);
     CTXALLOC(&P.counters, CCSP_CNT_COUNT * sizeof(unsigned long long));
+    CTXALLOC(&P.dbg, 64 * sizeof(unsigned long long));
+    CTXCHK(hipMemset(P.dbg, 0, 64 * sizeof(unsigned long long)));
     CTXALLOC(&P.stepacc, G * 8 * sizeof(uint32_t));
     CTXALLOC(&P.visit_hist, CCSP_NUM_ACTIONS * sizeof(unsigned long long));
     CTXALLOC(&P.log_count, sizeof(unsigned long long));
@@ -2071,6 +2100,15 @@ int ccsp_enable_tree_reuse(ccsp_ctx *ctx) {
     CTX_ENTER(ctx, nullptr);
     const int rc = ccsp_alloc_status(hipMalloc((void **)&ctx->P.pool2, ctx->pool_bytes), "hipMalloc(pool2)");
     if (rc != CCSP_OK) { ctx->P.pool2 = nullptr; return rc; }
+    return CCSP_OK;
+}
+
+int ccsp_debug_read(ccsp_ctx *ctx, unsigned long long *out /* [64] */, int clear) {
+    if (!ctx || !out) return CCSP_EINVAL;
+    CTX_ENTER(ctx, nullptr);
+    CCSP_HIPCHK(hipDeviceSynchronize());
+    CCSP_HIPCHK(hipMemcpy(out, ctx->P.dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (clear) CCSP_HIPCHK(hipMemset(ctx->P.dbg, 0, 64 * sizeof(unsigned long long)));
     return CCSP_OK;
 }
 

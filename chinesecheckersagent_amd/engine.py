@@ -123,6 +123,11 @@ class SelfPlayEngine(object):
         check(self.L.ccsp_read_counters(self.ctx, out.ctypes.data), 'ccsp_read_counters')
         return {name: int(out[_lib.CNT_INDEX[name]]) for name in CNT_NAMES}
 
+    def debug_read(self, clear=True):
+        out = np.zeros(64, dtype=np.uint64)
+        check(self.L.ccsp_debug_read(self.ctx, out.ctypes.data, int(clear)), 'ccsp_debug_read')
+        return [int(x) for x in out]
+
     def raw_counters(self):
         out = np.zeros(CNT_COUNT, dtype=np.uint64)
         check(self.L.ccsp_read_counters(self.ctx, out.ctypes.data), 'ccsp_read_counters')

@@ -183,8 +183,9 @@ class BatchSelfPlay(object):
 
     # ---- free-running stepping ---------------------------------------------------------------------------------------------
     FREE_UNROLL = 25         # [net -> advance | boundary] rounds per captured hipGraph
-    BOUNDARY_EVERY = 2       # ccsp_boundary in every k-th round only (a slot between two searches then waits up to k - 1 rounds;
-                             # measured at 4096 x 400: k = 1 / 2 / 3 -> 17.06 / 17.37 / 17.43 M node-expansions/s)
+    BOUNDARY_EVERY = 6       # ccsp_boundary in every k-th round only (a slot between two searches then waits up to k - 1 rounds;
+                             # measured at 4096 x 400 in steady state: k = 1 / 2 / 4 / 6 / 8 / 12 -> 17.1 / 17.4 / 18.24 / 18.32 / 18.26 / 18.15 M
+                             # node-expansions/s: beside an evaluator launch the boundary kernel's few long waves cost the round 30-40 us)
     DEBUG = False            # diagnostic tallies of ccsp_advance / ccsp_boundary in counters 12-14 (tools/bench_free.py --debug)
     SIDE_STREAM = False      # ccsp_boundary on a stream of its own beside the next evaluator launch (measured: hipGraphs with forks
                              # stop overlapping the two half-batches' graphs; kept for experiments)
@@ -266,10 +267,13 @@ class BatchSelfPlay(object):
                 ev0.record()
                 p, v = self._evaluate_free()
                 ev1.record()
-                self.net_events.append((ev0, ev1))
+                self._round(p, v)
+                ev2 = torch.cuda.Event(enable_timing=True)
+                ev2.record()
+                self.net_events.append((ev0, ev1, ev2))       # net launch | the round's tree kernels
             else:
                 p, v = self._evaluate_free()
-            self._round(p, v)
+                self._round(p, v)
             done += 1
         torch.cuda.current_stream().wait_stream(self._side)
         self.steps += n
@@ -410,13 +414,38 @@ class PipelinedSelfPlay(object):
                       for i in range(n_parts)]
         self.streams = [torch.cuda.Stream() for _ in range(n_parts)]
         self.max_games = max_games
+        self._forked = False
 
     def play_ply(self):
         cur = self.torch.cuda.current_stream()
+        if all(b.free_running for b in self.parts):
+            # Free-running parts: the rounds of a ply's worth are handed to the parts' streams ALTERNATELY, one captured graph at a time
+            # (a whole ply of part 0 first would leave part 1's stream empty for as long as the host takes to enqueue it: the halves
+            # would overlap for part of every ply only), and the streams are not joined ply by ply -- every read-back of the engines
+            # (harvest, counters, collect) synchronises the device itself.
+            if not self._forked:
+                for st in self.streams:
+                    st.wait_stream(cur)
+                self._forked = True
+            n, unroll = self.parts[0].sims + 1, BatchSelfPlay.FREE_UNROLL
+            done = 0
+            while done < n:
+                k = min(unroll, n - done)
+                for b, st in zip(self.parts, self.streams):
+                    with self.torch.cuda.stream(st):
+                        b.play_steps(k)
+                done += k
+            return
         for b, st in zip(self.parts, self.streams):
             st.wait_stream(cur)
             with self.torch.cuda.stream(st):
                 b.play_ply()
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def join(self):
+        """the parts' streams joined into the current one (free-running parts are not joined ply by ply)"""
+        cur = self.torch.cuda.current_stream()
         for st in self.streams:
             cur.wait_stream(st)
 
@@ -438,6 +467,7 @@ class PipelinedSelfPlay(object):
         return self.collect()
 
     def harvest(self):
+        self.join()
         return [h for b in self.parts for h in b.harvest()]
 
     def collect(self, allow_errors=False):

@@ -277,6 +277,8 @@ int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes,
 /* evaluator-free simulations (won leaves, reused positions) a slot may complete in ONE ccsp_advance (default 3: bounds the launch's
  * length; results do not depend on it; at least 1: a slot must be able to get past a won leaf).  Returns the previous value; n < 1 only reads it. */
 int ccsp_debug_advance_budget(int n);
+/* diagnostic: the cycle sums ccsp_advance keeps under CCSP_ADVANCE_DEBUG (64 words; see advance_kernel); clear != 0 zeroes them */
+int ccsp_debug_read(ccsp_ctx *ctx, unsigned long long *out, int clear);
 
 /* ---- evaluator: the policy/value network as one fused kernel (row N1; Model.predict, model.py:21-24) ---- */
 

@@ -17,14 +17,15 @@ ap.add_argument('--lockstep', action='store_true')
 ap.add_argument('--no-reuse', action='store_true')
 ap.add_argument('--side', action='store_true')
 ap.add_argument('--debug', action='store_true')
-ap.add_argument('--boundary-every', type=int, default=1)
+ap.add_argument('--boundary-every', type=int, default=0, help='0 = the class default')
 ap.add_argument('--harvest', type=int, default=4)
 ap.add_argument('--unroll', type=int, default=25)
 a = ap.parse_args()
 os.environ['CCSP_STRICT'] = '1'
 sp.BatchSelfPlay.SIDE_STREAM = a.side
 sp.BatchSelfPlay.DEBUG = a.debug
-sp.BatchSelfPlay.BOUNDARY_EVERY = a.boundary_every
+if a.boundary_every:
+    sp.BatchSelfPlay.BOUNDARY_EVERY = a.boundary_every
 sp.BatchSelfPlay.FREE_UNROLL = a.unroll
 m = ResidualCNN()
 m.load_weights('tests/golden/good_model.h5')
@@ -42,6 +43,10 @@ for kind, budget in cases:
     run.drain()
     torch.cuda.synchronize()
     raw0 = [sum(x) for x in zip(*[b.eng.raw_counters() for b in run.b.parts])] if a.debug else None
+    if a.debug:
+        [b.eng.debug_read(True) for b in run.b.parts]
+    for b_ in run.b.parts:
+        b_.net_events = []
     c0 = run.counters(); t0 = time.time()
     for _ in range(a.plies):
         run.play_ply()
@@ -49,6 +54,10 @@ for kind, budget in cases:
     dt = time.time() - t0
     c1 = run.counters()
     run.drain()
+    evs = [ev for b_ in run.b.parts for ev in (b_.net_events or [])]
+    if evs:
+        nets = sorted(e[0].elapsed_time(e[1]) for e in evs); trees = sorted(e[1].elapsed_time(e[2]) for e in evs)
+        print('in situ (uncaptured rounds, %d samples): net median %.1f us (min %.1f max %.1f), tree kernels median %.1f us (min %.1f max %.1f)' % (len(evs), nets[len(nets)//2]*1e3, nets[0]*1e3, nets[-1]*1e3, trees[len(trees)//2]*1e3, trees[0]*1e3, trees[-1]*1e3), flush=True)
     d = {k: c1[k] - c0[k] for k in c1}
     evals = a.plies * (a.sims + 1) * a.games
     print(json.dumps(dict(kind=kind, budget=budget, exp_per_s=d['expansions'] / dt, ms_per_play_ply=dt / a.plies * 1e3,
@@ -58,5 +67,9 @@ for kind, budget in cases:
     if a.debug:
         raw1 = [sum(x) for x in zip(*[b.eng.raw_counters() for b in run.b.parts])]
         calls = a.plies * (a.sims + 1) * a.games
+        dg = [sum(x) for x in zip(*[b.eng.debug_read(True) for b in run.b.parts])]
+        if dg[6]:
+            tick = 1e-2      # s_memtime ticks at 100 MHz: 10 ns
+            print('advance_kernel per call (us, s_memtime at 100 MHz): setup %.1f  expansion %.1f  backup %.1f  selection %.1f  encode %.1f  total %.1f (max %.1f); per call %.2f expansions, %.2f selections' % tuple([dg[i] / dg[6] * tick for i in (0, 1, 2, 3, 4, 5)] + [dg[9] * tick, dg[7] / dg[6], dg[8] / dg[6]]), flush=True)
         print(json.dumps(dict(requests_share=(raw1[12] - raw0[12]) / calls, log_guard_waits=(raw1[13] - raw0[13]), budget_idle_share=(raw1[14] - raw0[14]) / calls)), flush=True)
     run.close()

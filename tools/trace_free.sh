@@ -28,6 +28,10 @@ adv = [(e - s) / 1e3 for s, e, k, q in rows if k == 'adv']
 print('adv durations in launch order (us):', ' '.join('%.0f' % x for x in adv[3000:3200]))
 bnd = [(e - s) / 1e3 for s, e, k, q in rows if k == 'bnd']
 print('bnd durations in launch order (us):', ' '.join('%.0f' % x for x in bnd[3000:3200]))
+# per half-batch (the two parts' launches alternate in the serialised trace): mean of every 10 consecutive advance launches
+for half in (0, 1):
+    seq = adv[half::2][:3000]
+    print('adv half %d, means of 10 launches (us):' % half, ' '.join('%.0f' % (sum(seq[i:i + 10]) / len(seq[i:i + 10])) for i in range(0, len(seq), 10)))
 # a sample of the timeline
 for s, e, k, q in rows[2000:2040]: print('%8.1f %8.1f %s q=%s' % ((s - t0) / 1e3, (e - s) / 1e3, k, q))
 PY
