@@ -1680,8 +1680,14 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
             const bool last = spent >= budget;            // budget spent: one more selection, taken up only if it asks the evaluator
             SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
             uint32_t edges = 0;
-            const Leaf lf = reuse ? wave_select<false, false, true>(P.sqrt_tab, nullptr, cx, pool, path, sl.sim, mypath, myW, myN, edges)
-                                  : wave_select<false, false, false>(P.sqrt_tab, nullptr, cx, pool, path, sl.sim, mypath, myW, myN, edges);
+#ifndef CCSP_ADVANCE_RCP
+#define CCSP_ADVANCE_RCP 1
+#endif
+            // the two IEEE divisions per edge and level through the table of reciprocals (read from global memory here: 3.4 KB, cached --
+            // the LDS copy the fused kernel keeps would cost this kernel four of its workgroups per CU): 28 vector instructions fewer
+            // per edge; beside the evaluator every vector instruction of a tree wave waits for a gap between two MFMAs
+            const Leaf lf = reuse ? wave_select<CCSP_ADVANCE_RCP != 0, false, true>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges)
+                                  : wave_select<CCSP_ADVANCE_RCP != 0, false, false>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges);
             a_sims += 1; a_depth += (uint32_t)lf.depth; a_edges += edges;
             leaf = lf.st; leaf_player = lf.player; depth = lf.depth; link_off = lf.link_off;
             have_stats = true;

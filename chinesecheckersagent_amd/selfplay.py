@@ -207,7 +207,7 @@ class BatchSelfPlay(object):
         if not self.SIDE_STREAM:
             e.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, debug=self.DEBUG)
             self._round_no += 1
-            if self._round_no % self.BOUNDARY_EVERY == 0:
+            if self._round_no % (self.BOUNDARY_EVERY if self.n_slots >= 1024 else 1) == 0:      # (a small batch is latency-bound: no waiting there)
                 e.boundary(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, stagger=self.stagger, debug=self.DEBUG)
             return
         cur = torch.cuda.current_stream()

@@ -239,24 +239,6 @@ def test_iteration_pooling_and_paths(tmp_path):
     assert min(1. / 2, tr.DEF_DATA_RETENTION_RATE) == 0.5 and tr.NUM_SELF_PLAY == 180 and tr.EVAL_GAMES == 24
 
 
-def test_offline_data_tools(tmp_path):
-    """combine_data.py / count_labels.py on h5lite files"""
-    from chinesecheckersagent_amd import datatools, utils
-    rng = np.random.RandomState(8)
-    d = str(tmp_path)
-    sizes = {2: 5, 3: 7, 5: 3}
-    data = {}
-    for v, n in sizes.items():
-        data[v] = (rng.rand(n, 7, 7, 7), rng.rand(n, 294), rng.randint(-1, 2, size=n))
-        utils.save_train_data(*data[v], version=v, directory=d)
-    bx, py, vy, used = datatools.combine_train_data([], [], [], 1, 5, d, 'data-for-iter-')
-    assert used == 3 and len(bx) == 15 and np.array_equal(bx[:5], data[2][0]) and np.array_equal(vy[-3:], data[5][2])
-    out = datatools.save_combined(bx, py, vy, path=str(tmp_path / 'combined.h5'))
-    cnt = datatools.get_train_label_count(out)
-    assert sum(cnt.values()) == 15 and cnt == datatools.count_items(np.hstack([data[v][2] for v in (2, 3, 5)]))
-    assert datatools.combine_train_data([], [], [], 8, 9, d, 'data-for-iter-') == ([], [], [], 0)
-
-
 def test_against_keras_step_when_present(golden_dir):
     """pins next-2 once somebody has run oracle/harness/gen_keras_train_golden.py where Keras exists: one optimisation step
     on the same batch from the same weights -- total loss and every updated tensor (BatchNorm moving statistics included)"""
