@@ -603,7 +603,7 @@ class SelfPlayRun(object):
 
     def __init__(self, model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False, first_game=0,
                  game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY, use_graph=True, keep_records=True,
-                 sink=None, n_parts=None, free_running=True, reuse=None):
+                 sink=None, n_parts=None, free_running=None, reuse=None):
         tune_host_allocator()
         _lib.prefer_blocking_sync()                        # (effective when the process has not touched the GPU yet)
         n_games = int(n_games)
@@ -615,6 +615,11 @@ class SelfPlayRun(object):
         kw = dict(sims=sims, seed=seed, first_game=first_game, game_stride=game_stride, max_games=n_games, randomised=randomised,
                   auto_restart=True, device=device, use_graph=use_graph)
         cap = n_slots * (self.harvest_every + 1)
+        if free_running is None:
+            # a batch that does not fill the GPU is latency-bound: a lock-step round (net -> one tree kernel) is shorter than a
+            # free-running one (256 games x 800 simulations: 7.6 s lock-step, 8.4-8.6 s free-running although a quarter of the
+            # expansions come from the previous tree); from about a thousand slots on the free-running form wins (4096: +19 %)
+            free_running = n_slots >= 1024
         if free_running and hasattr(_batched(model1), 'model'):
             # slots run at their own pace (BatchSelfPlay): between two harvests a slot plays up to ~1.5 plies per `play_ply`; a slot that
             # could find the log full waits for the harvest (log_guard) instead of losing a row

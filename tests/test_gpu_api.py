@@ -331,7 +331,8 @@ def test_restarting_slots_return_the_records_of_one_slot_per_game(golden_dir, tm
     b.close()
     assert all(h != 'unfinished' for h, _ in want)
     assert any(h is None for h, _ in want) and any(isinstance(h, list) for h, _ in want)     # both kinds of ending occur
-    for kw in (dict(max_slots=5, harvest_every=3), dict(max_slots=8, harvest_every=16, n_parts=2), dict(max_slots=64, harvest_every=7)):
+    for kw in (dict(max_slots=5, harvest_every=3), dict(max_slots=8, harvest_every=16, n_parts=2), dict(max_slots=64, harvest_every=7),
+               dict(max_slots=5, harvest_every=3, free_running=True), dict(max_slots=8, harvest_every=2, n_parts=2, free_running=True)):
         run = sp.SelfPlayRun(m, n_games=n, sims=sims, seed=seed, first_game=first, **kw)
         got = _records(run.run().games())
         c = run.counters()

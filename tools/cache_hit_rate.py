@@ -45,6 +45,7 @@ def play(job):
         pos, last, w = orc.step(pos, last, player, cid, dest)
         player, ply = 3 - player, ply + 1
     prev = None
+    prev2 = None
     rows = []
     for _ in range(plies):
         del seen_now[:]
@@ -54,8 +55,10 @@ def play(job):
         chosen = [j for j in range(o.n_root) if o.id[j] == o.chosen_id and o.dest[j] == o.chosen_dest][0]
         if prev is not None:
             hits = sum(1 for k in cur if k in prev)
-            rows.append(dict(ply=ply, calls=len(cur), hit_any=hits, distinct=len(set(cur))))
+            hits2 = sum(1 for k in cur if (k not in prev) and prev2 is not None and (k in prev2))
+            rows.append(dict(ply=ply, calls=len(cur), hit_any=hits, hit_two_plies_ago_only=hits2, distinct=len(set(cur))))
         rows[-1:] and rows[-1].update(chosen_N=int(o.N[chosen]), top_N=root_N[:3])
+        prev2 = prev
         prev = set(cur)
         pos, last, w = orc.step(pos, last, player, o.chosen_id, o.chosen_dest)
         player, ply = 3 - player, ply + 1
@@ -78,7 +81,8 @@ def main():
     hits = sum(r['hit_any'] for g in games for r in g['rows'])
     early = [r for g in games for r in g['rows'] if r['ply'] < 16]
     late = [r for g in games for r in g['rows'] if r['ply'] >= 16]
-    doc = dict(sims=a.sims, games=a.games, calls=calls, hits=hits, hit_rate=hits / max(calls, 1),
+    hits2 = sum(r.get('hit_two_plies_ago_only', 0) for g in games for r in g['rows'])
+    doc = dict(sims=a.sims, games=a.games, calls=calls, hits=hits, hit_rate=hits / max(calls, 1), extra_hit_rate_with_two_plies=hits2 / max(calls, 1),
                hit_rate_tau1=sum(r['hit_any'] for r in early) / max(1, sum(r['calls'] for r in early)),
                hit_rate_tau001=sum(r['hit_any'] for r in late) / max(1, sum(r['calls'] for r in late)),
                per_game=[sum(r['hit_any'] for r in g['rows']) / max(1, sum(r['calls'] for r in g['rows'])) for g in games])
