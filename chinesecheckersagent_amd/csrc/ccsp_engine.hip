@@ -151,7 +151,7 @@ struct Lds {                      // per-wave scratch (one wave per workgroup)
     EngineLines T;                // line tables, copied from device constant data
     uint32_t lines[32];           // occupancy pattern of the 27 board lines for the position being expanded
     uint8_t lists[6][24];
-    union {
+    union __attribute__((aligned(4))) {
         uint8_t stack[6][96];     // depth-first stacks of wave_movegen (<= 6 pushes per visited sub-lattice cell)
         uint8_t img[CCSP_PLANES + 1];   // wave_encode's byte image (never alive while a move list is being generated)
     };
@@ -648,14 +648,32 @@ __device__ __forceinline__ void wave_backup(uint8_t *pool, const uint64_t *path,
 
 // ---- C1 for one position into planes[343] (stepped path) --------------------------------------------
 __device__ __forceinline__ void wave_encode(Lds &lds, const ccsp_sr &st, int player, float *out) {
+    // the byte image of the 343 values (ids 1..6 scattered by twelve lanes, the player-two flag in channel 6 of every cell), then
+    // four bytes -> four floats -> one 16-byte store per lane and pass: 86 dwords, two passes (beside the evaluator every vector
+    // instruction of a tree wave waits for a gap between MFMAs: 35 of them here instead of a hundred)
     const int lane = lane_id();
+    static_assert(sizeof(lds.img) >= 344 && (CCSP_PLANES + 1) % 4 == 0, "the image is cleared and read as 86 dwords");
+    uint32_t *img4 = reinterpret_cast<uint32_t *>(&lds.img[0]);
     __syncthreads();
-    for (int i = lane; i < CCSP_PLANES; i += 64) lds.img[i] = 0;
+    img4[lane] = 0u;
+    if (lane < 22) img4[64 + lane] = 0u;
     __syncthreads();
+    if (player == 2 && lane < CCSP_NCELL) lds.img[lane * 7 + 6] = 1;             // utils.py:157-158
     if (lane < 12) ccsp_scatter_checker(st, player, lane, &lds.img[0]);
     __syncthreads();
-    const float flag = player == 2 ? 1.0f : 0.0f;
-    for (int i = lane; i < CCSP_PLANES; i += 64) out[i] = (i % 7 == 6) ? flag : (float)lds.img[i];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int d = lane + 64 * pass;                                          // dword 0 .. 85 = values 4 d .. 4 d + 3
+        if (d < 85) {
+            const uint32_t w = img4[d];
+            struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; } f;          // (a slot's 1372-byte row is 4-byte aligned, not 16)
+            f.x = (float)(w & 0xFFu); f.y = (float)((w >> 8) & 0xFFu); f.z = (float)((w >> 16) & 0xFFu); f.w = (float)(w >> 24);
+            *reinterpret_cast<F4 *>(out + 4 * d) = f;
+        } else if (d == 85) {                                                    // values 340, 341, 342 (343 is not a multiple of four)
+            const uint32_t w = img4[85];
+            out[340] = (float)(w & 0xFFu); out[341] = (float)((w >> 8) & 0xFFu); out[342] = (float)((w >> 16) & 0xFFu);
+        }
+    }
 }
 
 // ---- game bookkeeping ----------------------------------------------------------------------------------
