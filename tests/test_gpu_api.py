@@ -435,6 +435,16 @@ def test_free_running_slots_play_the_lock_step_games(golden_dir):
     assert got2 == want2
     with pytest.raises(ValueError):
         sp.BatchSelfPlay(m, m2, n_slots=2, sims=4, free_running=True, reuse=True)
+    # Board(randomised=True) starts with ONE model (tree reuse on), more simulations, restarting slots through SelfPlayRun
+    kw = dict(sims=50, seed=43, first_game=7000, randomised=True)
+    b = sp.BatchSelfPlay(m, n_slots=12, max_games=12, log_capacity=12 * 600, **kw)
+    want3 = _records(b.run_to_completion(max_plies=1100))
+    b.close()
+    run = sp.SelfPlayRun(m, n_games=12, max_slots=5, harvest_every=2, free_running=True, **kw)
+    got3 = _records(run.run().games())
+    c3 = run.counters()
+    run.close()
+    assert got3 == want3 and c3['errors'] == 0 and c3['cache_hits'] > 0
 
 
 def test_config1_one_whole_game_50_sims_matches_oracle(golden_dir):
