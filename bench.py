@@ -766,6 +766,36 @@ def extras(eng, G, S, torch, _lib, engine):
     v['2b_rollout'] = {'node_expansions_per_s': (c1['expansions'] - c0['expansions']) / wall, 'ms_per_ply': kms,
                        'workload': '%d games x %d sims, v = random playout <= 64 plies, p = 1/294' % (G, S)}
     e.close()
+    # config 3 in LOCK-STEP (round 3's delivered mode, still what small batches and the arena use): every slot at the same simulation of
+    # the same ply, no tree reuse -- so that the record shows what the free-running path is measured against, and the evaluator's
+    # in-pipeline figure when one tree launch per round hides under the other half-batch's evaluator launch
+    if weights_path() and G >= 2048:
+        from chinesecheckersagent_amd import selfplay as sp
+        from chinesecheckersagent_amd.model import ResidualCNN
+        m = ResidualCNN(device='cuda:%d' % torch.cuda.current_device())
+        m.load_weights(weights_path())
+        sink = sp.TrainDataSink(); sink.discard = True
+        run = sp.SelfPlayRun(m, n_games=G * 64, sims=S, seed=SEED, max_slots=G, keep_records=False, sink=sink, free_running=False)
+        try:
+            for _ in range(80):                            # (as many untimed plies as the headline's spread + warm-up: the same steady state)
+                run.play_ply()
+            run.drain()
+            torch.cuda.synchronize()
+            c0 = run.counters(); t0 = time.time()
+            for _ in range(8):
+                run.play_ply()
+            torch.cuda.synchronize()
+            wall = time.time() - t0
+            c1 = run.counters()
+            parts = len(run.b.parts) if hasattr(run.b, 'parts') else 1
+            launches = 8 * (S + 1) * parts
+            v['3_lock_step'] = {'node_expansions_per_s': (c1['expansions'] - c0['expansions']) / wall, 'ms_per_step': wall / 8 * 1e3,
+                                'games_per_s': (c1['games_won'] + c1['games_discarded'] - c0['games_won'] - c0['games_discarded']) / wall,
+                                'evaluator_wall_ms_per_launch': wall / launches * 1e3,
+                                'evaluator_wall_frac': (run.n_slots // parts) * NET_FLOP_PER_EVAL / (wall / launches) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                'workload': 'config 3 with lock-step slots (SelfPlayRun(free_running=False)): 80 untimed + 8 timed plies, no conversion sink'}
+        finally:
+            run.close()
     # games/s with a TABLE evaluator under which games END in wins (the uniform one of 2a never wins: every game is discarded
     # by the no-progress rule): spec.forward_eval, parity-pinned like 2a; steady state with restarts
     e = engine.SelfPlayEngine(n_slots=G, sims=S, seed=SEED, max_games=G * 64, log_capacity=G * 160, auto_restart=True)
