@@ -549,6 +549,26 @@ def test_generate_self_play_in_parallel_world2_on_one_device(golden_dir):
     assert sum(summ['visit_histogram']) == c['mcts_plies'] * sims
     bx, py, vy = sp.generate_self_play_in_parallel(w, n, 2, sims=sims, seed=seed, first_game=first, devices=[0, 0], as_arrays=True)
     assert len(vy) == sum(len(h) for h, _ in one)
+    from chinesecheckersagent_amd import utils
+    wx, wp, wv = utils.convert_to_train_data(one)
+    assert (np.array(wx) == bx).all() and (np.array(wp) == py).all() and list(vy) == wv
+    # at a real size: 2600 games through two ranks of 1024 FREE-RUNNING slots each (every slot restarts), the rows streamed into the
+    # ranks' files (worker --arrays) and merged by game id == the arrays one process generates
+    n, sims, first = 2600, 5, 9000
+    (bx, py, vy), summ = sp.generate_self_play_in_parallel(w, n, 2, sims=sims, seed=seed, first_game=first, devices=[0, 0], as_arrays=True,
+                                                           return_summary=True, max_slots=1024, timeout=600)
+    ox, op, ov, osum = sp.generate_train_data(ResidualCNN_loaded(w), n_games=n, sims=sims, seed=seed, first_game=first, max_slots=2048)
+    c = summ['counters']
+    assert c['errors'] == 0 and c['games_won'] + c['games_discarded'] == n and c['cache_hits'] > 0
+    assert c['games_won'] == osum['won'] and c['expansions'] == osum['counters']['expansions']
+    assert len(vy) == len(ov) > 0 and (bx == ox).all() and (py == op).all() and (vy == ov).all()
+
+
+def ResidualCNN_loaded(path):
+    from chinesecheckersagent_amd.model import ResidualCNN
+    m = ResidualCNN()
+    m.load_weights(path)
+    return m
 
 
 def _bench(extra, **envx):
