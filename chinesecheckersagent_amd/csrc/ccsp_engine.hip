@@ -1027,21 +1027,34 @@ __device__ __forceinline__ void fast_forward_opening(const Params &P, Lds &lds, 
     while (sl.status == CCSP_ST_RUNNING && sl.opening_left > 0) wave_opening_ply(P, lds, sl, tl);
 }
 
-// NumPy pairwise summation of 294 float64 (np.sum at MCTS.py:137), serial
-__device__ __forceinline__ double pairwise_block(const double *a, int n) {          // n <= 128, n >= 8
-    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8) {
-        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
-        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+// NumPy pairwise summation of 294 float64 (np.sum at MCTS.py:137) on 32 lanes: NumPy's order is 294 -> (72 + 72) + (72 + 78),
+// each block = 8 strided accumulators (nine terms each) combined as
+// ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), the last block's six left-over terms added to ITS result one after the other, then
+// (b0 + b1) + (b2 + b3).  Lane 8 b + k runs accumulator k of block b; the pair sums go through lane exchanges in exactly that
+// shape (IEEE addition commutes: which of a pair's lanes holds which term does not matter).  Same bits as the serial form, a ninth of
+// its length -- at a ply boundary the wave sits beside an evaluator launch, where a dependent f64 addition takes five times as long.
+__device__ __forceinline__ double wave_pairwise_294(const double *a) {
+    const int lane = lane_id();
+    const int blk = (lane >> 3) & 3, k = lane & 7;
+    const double *base = a + 72 * blk;
+    double r = base[k];
+#pragma unroll
+    for (int g = 1; g < 9; g++) r += base[8 * g + k];
+    auto xchg = [](double x, int m) -> double {
+        const uint64_t u = ccsp_to_bits(x);
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)u, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(u >> 32), m);
+        return ccsp_from_bits(((uint64_t)hi << 32) | lo);
+    };
+    r = r + xchg(r, 1);                                   // r0 + r1, r2 + r3, r4 + r5, r6 + r7
+    r = r + xchg(r, 2);                                   // (r0 + r1) + (r2 + r3), (r4 + r5) + (r6 + r7)
+    r = r + xchg(r, 4);                                   // the block's sum, in all eight lanes of the block
+    if (blk == 3) {                                       // 294 = 3 x 72 + 78: the last block's tail
+#pragma unroll
+        for (int i = 72; i < 78; i++) r += base[i];
     }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += a[i];
-    return res;
-}
-__device__ __forceinline__ double pairwise_294(const double *a) {
-    // 294 -> 144 + 150 -> (72 + 72) + (72 + 78)
-    return (pairwise_block(a, 72) + pairwise_block(a + 72, 72)) + (pairwise_block(a + 144, 72) + pairwise_block(a + 216, 78));
+    r = r + xchg(r, 8);                                   // b0 + b1, b2 + b3
+    r = r + xchg(r, 16);                                  // (b0 + b1) + (b2 + b3)
+    return ccsp_from_bits(uni64(ccsp_to_bits(r)));        // lane 0's copy (lanes 32 .. 63 computed the same)
 }
 
 // T4 + end of make_move: pi from the root's visit counts, action sampling, sample-log row, Board.place
@@ -1073,9 +1086,7 @@ __device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot 
     // handing back pi = inf / inf.  Searches of up to 1209 simulations cannot get there.
     if (__ballot(overflow)) { sl.status = CCSP_ST_ERROR; slot_finish(P, lds, sl, CCSP_ST_ERROR, tl); return; }
     __syncthreads();
-    if (lane == 0) lds.gam[CCSP_MAX_MOVES] = pairwise_294(lds.pi);            // np.sum, MCTS.py:137
-    __syncthreads();
-    const double s = lds.gam[CCSP_MAX_MOVES];
+    const double s = wave_pairwise_294(lds.pi);                               // np.sum, MCTS.py:137
     for (int i = lane; i < CCSP_NUM_ACTIONS; i += 64) lds.pi[i] = lds.pi[i] / s;
     __syncthreads();
     // play_history.append((root.state, pi)) (selfplay.py:128) -> one row of the sample log
@@ -1092,30 +1103,43 @@ __device__ __forceinline__ void wave_finish_ply(const Params &P, Lds &lds, Slot 
         for (int i = lane; i < CCSP_NUM_ACTIONS; i += 64) dst[i] = lds.pi[i];
     }
     __syncthreads();
-    // np.random.choice(294, p=pi) stand-in (spec.sample_index): cumsum, / last, first cdf > u.  The running sums are ONE chain of 294
-    // additions in index order (lane 0, in place over pi: the log row is written); the 294 divisions and comparisons do not depend on
-    // one another: every lane tests its own entries and a ballot finds the first index that passes -- the serial scan's pick
-    static_assert(CCSP_NUM_ACTIONS % 6 == 0, "the running sums are unrolled by six");
+    // np.random.choice(294, p=pi) stand-in (spec.sample_index): cumsum, / last, first cdf > u.  pi is zero outside the root's K edges
+    // and x + 0.0 = x: the running sum only moves at the edges' entries, and the first index that passes the test is one of them.
+    // So: the K edges ranked by action index (a 294-bit mask in LDS, popcounts below each one's bit), their values laid out in that
+    // order, ONE chain of K additions instead of 294 (lane 0), then every lane tests its own entries and a ballot finds the first
+    // that passes -- the serial scan's pick, at an eighth of its length.
+    uint32_t *mask = &lds.lines[0];                       // 10 words (the line patterns are not alive at a ply's end)
+    uint16_t *sorted_a = reinterpret_cast<uint16_t *>(&lds.stack[0][0]);       // [K] action index by rank (the hop stacks are not alive either)
+    double *sorted_c = &lds.gam[0];                       // [K] value, then running sum, by rank
+    if (lane < 10) mask[lane] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) if (lane + 64 * h < K) atomicOr(&mask[mvs[h] >> 5], 1u << (mvs[h] & 31));
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (lane + 64 * h < K) {
+            const int w = (int)(mvs[h] >> 5);
+            int r = __popc(mask[w] & ((1u << (mvs[h] & 31)) - 1u));
+            for (int i = 0; i < w; i++) r += __popc(mask[i]);
+            sorted_a[r] = (uint16_t)mvs[h];
+            sorted_c[r] = lds.pi[mvs[h]];
+        }
+    }
+    __syncthreads();
     if (lane == 0) {
         double c = 0.0;
-        for (int i = 0; i < CCSP_NUM_ACTIONS; i += 6) {
-            const double a0 = lds.pi[i], a1 = lds.pi[i + 1], a2 = lds.pi[i + 2], a3 = lds.pi[i + 3], a4 = lds.pi[i + 4], a5 = lds.pi[i + 5];
-            c = c + a0; lds.pi[i] = c; c = c + a1; lds.pi[i + 1] = c; c = c + a2; lds.pi[i + 2] = c;
-            c = c + a3; lds.pi[i + 3] = c; c = c + a4; lds.pi[i + 4] = c; c = c + a5; lds.pi[i + 5] = c;
-        }
+        for (int r = 0; r < K; r++) { c = c + sorted_c[r]; sorted_c[r] = c; }
     }
     __syncthreads();
     int pick = CCSP_NUM_ACTIONS - 1;
     {
         const double u = (double)(ccsp_rng_from(sl.hgame, sl.ply, 0, 0, CCSP_P_SAMPLE) >> 11) * 1.1102230246251565e-16;
-        const double last = lds.pi[CCSP_NUM_ACTIONS - 1];
-        bool seen = false;
-#pragma unroll
-        for (int r = 0; r < (CCSP_NUM_ACTIONS + 63) / 64; r++) {
-            const int i = lane + 64 * r;
-            const uint64_t hit = __ballot(i < CCSP_NUM_ACTIONS && lds.pi[i < CCSP_NUM_ACTIONS ? i : 0] / last > u);
-            if (!seen && hit) { pick = 64 * r + ccsp_ctz64(hit); seen = true; }
-        }
+        const double last = sorted_c[K - 1];
+        const uint64_t hit_lo = __ballot(lane < K && sorted_c[lane < K ? lane : 0] / last > u);
+        const uint64_t hit_hi = __ballot(lane + 64 < K && sorted_c[lane + 64 < K ? lane + 64 : 0] / last > u);
+        if (hit_lo) pick = (int)sorted_a[ccsp_ctz64(hit_lo)];
+        else if (hit_hi) pick = (int)sorted_a[64 + ccsp_ctz64(hit_hi)];
     }
     const int cid = pick / CCSP_NCELL, cdest = pick % CCSP_NCELL;
     const uint32_t pick_idx = (uint32_t)pick;
