@@ -536,6 +536,9 @@ def main():
                                     'tree_reuse_hit_rate': tot3.get('cache_hits', 0) / max(ex, 1),
                                     'terminal_sim_share': tot3['terminal_sims'] / max(tot3['sims'], 1),
                                     'searched_plies_per_slot_per_step': tot3['mcts_plies'] / max(steps * info['n_slots'] * world, 1),
+                                    # free-running slots do not share a ply: the time in which every slot searches ONE ply on average
+                                    # (what `ms_per_step` was in the lock-step form, where a step is a ply of every slot)
+                                    'ms_per_searched_ply_of_every_slot': dt3 * 1e3 * info['n_slots'] * world / max(tot3['mcts_plies'], 1),
                                     'free_running': info['free_running'],
                                     'train_rows_per_s': rows_all / dt3,
                                     'host_cpu_s_per_rank': [h[0] for h in host], 'host_cpu_cores_busy_per_rank': [h[0] / dt3 for h in host],

@@ -36,8 +36,9 @@ for r in csv.DictReader(open(sys.argv[1])):
 # net_forward_kernel: the launches of the timed region sit in hipGraphs beside the other half-batch's tree kernels; the LAST 400
 # launches of the trace are bench.py's back-to-back burst (the figure `roofline.avg_launch_ms` reports)
 net.sort()
-big = [d for _, d, g in net if g == max(g_ for _, _, g_ in net)]
-full = [(st, d) for st, d, g in net if g == max(g_ for _, _, g_ in net)]
+gmax = max([g for _, _, g in net] or [0])
+big = [d for _, d, g in net if g == gmax]
+full = [(st, d) for st, d, g in net if g == gmax]
 if len(full) > 900:
     pp = full[:-500]                                   # the launches inside the timed pipelines, in start order
     gaps = [pp[i + 1][0] - (pp[i][0] + pp[i][1]) for i in range(len(pp) - 1)]
