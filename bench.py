@@ -553,28 +553,38 @@ def main():
             'mean_depth': tot3['sum_depth'] / max(tot3['sims'], 1), 'mean_children': tot3['sum_children'] / max(ex, 1),
             'errors': tot3['errors'], 'per_rank_expansions': per3, 'precision': 'fp32', 'backend': info['backend'],
             'target_node_expansions_per_s_per_gpu': 1e6,
-            # `achieved` / `frac` describe the kernel AS THE PRODUCT RUNS IT: the median duration of the evaluator launches of the timed
-            # region's uncaptured steps (one per half-batch and timed ply), each between two HIP events on the stream it is launched on,
-            # while the other half-batch's captured graphs -- evaluator and tree kernels -- run beside it.  Kept beside it: the kernel
-            # alone (*_isolated: a back-to-back burst after the timed region) and the timed plies' wall time per evaluator launch
-            # (wall_ms_per_launch: what a launch COSTS the pipeline, tree kernels that do not hide under the other half's launch included).
-            'roofline': (lambda k_in: {
+            # `achieved` / `frac` describe the kernel AS THE PRODUCT RUNS IT.  `avg_launch_ms` = the median duration of the evaluator launches
+            # of the timed region's uncaptured steps (one per half-batch and timed ply), each between two HIP events on the stream it is
+            # launched on, while the other half-batch's captured graphs -- evaluator and tree kernels -- run beside it; rocprofv3's
+            # average over the same run (profiles/r4_bench_kernel_stats.csv) agrees with it.  Since the tree kernels of a round are shorter
+            # than an evaluator launch, the two half-batches' evaluator launches OVERLAP (profiles/r4_launches.csv: the next launch
+            # starts ~28 us before the previous one ends): each then shares the matrix pipes with the other and its own duration says how
+            # long it was in flight, not how much of the device it used.  `launches_in_flight` = avg_launch_ms / wall_ms_per_launch (the
+            # timed plies' wall time / evaluator launches in them); above 1 the device time a launch consumed is its duration divided
+            # by that number (= the wall time per launch: gaps between launches count against the kernel), which is what `achieved` is
+            # computed from; at or below 1 (no overlap) from the launch's own duration.  Kept beside it: the figure by a launch's own
+            # duration whatever the overlap (*_by_launch_duration) and the kernel alone (*_isolated: a back-to-back burst after the timed region).
+            'roofline': (lambda k_in, wall_ms: (lambda eff_ms: {
                          'bound': 'mfma', 'dtype': 'fp32', 'kernel': 'net_forward_kernel',
-                         'achieved': info['n_pos'] * NET_FLOP_PER_EVAL / (k_in * 1e-3) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS,
+                         'achieved': info['n_pos'] * NET_FLOP_PER_EVAL / (eff_ms * 1e-3) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS,
                          'unit': 'TFLOP/s',
-                         'frac': info['n_pos'] * NET_FLOP_PER_EVAL / (k_in * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         'frac': info['n_pos'] * NET_FLOP_PER_EVAL / (eff_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          'traffic': None,
                          'flop_per_position': NET_FLOP_PER_EVAL, 'positions_per_launch': info['n_pos'],
                          'avg_launch_ms': k_in,
-                         'how': ('median of %d launches inside the timed region, HIP events on the launching stream, the other half-batch running beside them'
-                                 % info['net_in_pipeline_samples']) if info.get('net_in_pipeline_ms') else
+                         'launches_in_flight': k_in / wall_ms,
+                         'device_ms_per_launch': eff_ms,
+                         'how': ('avg_launch_ms: median of %d launches inside the timed region, HIP events on the launching stream, the other half-batch running beside them; '
+                                 'achieved = FLOP per launch / (avg_launch_ms / max(1, launches_in_flight))' % info['net_in_pipeline_samples'])
+                                if info.get('net_in_pipeline_ms') else
                                 'wall time of the timed plies / evaluator launches in them (no uncaptured step to put events around)',
                          'launches_in_timed_region_per_gpu': launches,
+                         'frac_by_launch_duration': info['n_pos'] * NET_FLOP_PER_EVAL / (k_in * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          'achieved_isolated': tf, 'frac_isolated': tf / MFMA_F32_PEAK_TFLOPS, 'avg_launch_ms_isolated': k_ms,
                          'tree_kernels_ms_in_the_same_rounds': info.get('tree_in_pipeline_ms'),      # advance (+ boundary) of the timed round, same events
-                         'wall_ms_per_launch': max(h[2] for h in host) / launches * 1e3,
-                         'wall_frac': info['n_pos'] * NET_FLOP_PER_EVAL / (max(h[2] for h in host) / launches) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         })(max_over_ranks_in(info)),
+                         'wall_ms_per_launch': wall_ms,
+                         'wall_frac': info['n_pos'] * NET_FLOP_PER_EVAL / (wall_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         })(k_in / max(1.0, k_in / wall_ms)))(max_over_ranks_in(info), max(h[2] for h in host) / launches * 1e3),
         }
         try:                                 # HBM bytes of one launch by the counters (static: a --pmc pass cannot run inside this process)
             prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))['net_forward_kernel']

@@ -82,7 +82,10 @@ _SIGS = {
     'ccsp_advance': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
     'ccsp_boundary': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
     'ccsp_debug_advance_budget': (C.c_int, [C.c_int]),
+    'ccsp_debug_advance_time_cap': (C.c_int, [C.c_int]),
+    'ccsp_debug_advance_deadline': (C.c_int, [C.c_int]),
     'ccsp_debug_read': (C.c_int, [_VP, _VP, C.c_int]),
+    'ccsp_debug_read_slots': (C.c_int, [_VP, _VP]),
     'ccsp_read_counters': (C.c_int, [_VP, _VP]),
     'ccsp_read_visit_histogram': (C.c_int, [_VP, _VP]),
     'ccsp_read_slots': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),

@@ -87,6 +87,7 @@ struct Pending {                  // select -> expand_backup hand-off of the ste
 };
 static_assert(sizeof(Pending) == 64, "Pending must stay 64 bytes");
 
+constexpr int CCSP_DBG_STRIDE = CCSP_DEBUG_WORDS_PER_SLOT;
 struct Params {
     SlotMem *slots;
     Pending *pend;
@@ -99,7 +100,7 @@ struct Params {
     const double *pow_tab;
     const double *rcp_tab;        // 1/i, max(sims + 2, RCP_N) entries
     unsigned long long *counters;
-    unsigned long long *dbg;      // [64] diagnostic cycle sums of advance_kernel (CCSP_ADVANCE_DEBUG; ccsp_debug_read)
+    unsigned long long *dbg;      // [n_slots][CCSP_DBG_STRIDE] diagnostic cycle sums of advance_kernel per slot (CCSP_ADVANCE_DEBUG; ccsp_debug_read adds them up)
     uint32_t *stepacc;            // [n_slots][8] per-slot tallies of the stepped path (flushed once per ply: no
                                   // global atomics inside the per-simulation kernels)
     unsigned long long *visit_hist;
@@ -124,7 +125,7 @@ constexpr int RCP_N = 422;          // reciprocal table entries kept in LDS by t
 // The line tables of ccsp_rules.h as the engine's one-wave workgroups keep them in LDS: both senses of a hop in ONE byte (two 3-bit
 // landing positions, 7 = none) -- 1340 bytes instead of 2236.  With the evaluator's 137-KB workgroup on a CU every byte of a tree
 // workgroup decides how many of them fit beside it (advance_kernel: 2.2 KB = ten; 3.1 KB was seven).
-struct EngineLines {
+struct alignas(16) EngineLines {           // (1344 bytes with its tail padding: copied as 84 x 16 bytes)
     uint8_t lp[CCSP_NCELL][4];          // [cell][axis] = line << 3 | position
     uint8_t cell[CCSP_NLINES][8];       // [line][position]
     uint8_t base[CCSP_NLINES + 5];      // off-board bits of each line's pattern
@@ -141,10 +142,17 @@ static constexpr EngineLines make_engine_lines() {
     return e;
 }
 static __device__ const EngineLines ENGINE_LINES_DEV = make_engine_lines();
+// one wave copies the tables: two 16-byte loads per lane, both in flight before either is waited for (as a loop of dwords the copy was
+// six dependent round trips at the head of every launch of every stepped kernel)
 __device__ __forceinline__ void load_engine_lines(EngineLines *lds, int tid) {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&ENGINE_LINES_DEV);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
-    for (int i = tid; i < (int)(sizeof(EngineLines) / 4); i += 64) dst[i] = src[i];
+    constexpr int N16 = (int)(sizeof(EngineLines) / 16);
+    static_assert(sizeof(EngineLines) % 16 == 0 && N16 > 64 && N16 <= 128, "two passes of 64 lanes x 16 bytes");
+    const uint4 *src = reinterpret_cast<const uint4 *>(&ENGINE_LINES_DEV);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    const int second = tid + 64 < N16 ? tid + 64 : tid;
+    const uint4 a = src[tid], b = src[second];
+    dst[tid] = a;
+    if (tid + 64 < N16) dst[tid + 64] = b;
 }
 
 struct Lds {                      // per-wave scratch (one wave per workgroup)
@@ -219,6 +227,27 @@ __device__ __forceinline__ double wave_max_f64(double x) {
     const uint32_t ml = wave_max_u32(kh == mh ? kl : 0u);
     const uint32_t back = (mh & 0x80000000u) ? 0u : 0xFFFFFFFFu;
     return ccsp_from_bits(((uint64_t)(mh ^ (back | 0x80000000u)) << 32) | (uint64_t)(ml ^ back));
+}
+
+// wave_max_f64 that stops after the high words when exactly one lane holds the largest: `eq_high` = the lanes with the largest high
+// word, `unique` = there is one (then mx is not computed: the caller reads that lane's value)
+struct KeyMax { uint64_t eq_high; bool unique; double mx; };
+__device__ __forceinline__ KeyMax wave_max_f64_key(double x) {
+    const uint64_t b = ccsp_to_bits(x);
+    const uint32_t h = (uint32_t)(b >> 32), l = (uint32_t)b;
+    const uint32_t neg = (uint32_t)((int32_t)h >> 31);
+    const uint32_t kh = h ^ (neg | 0x80000000u), kl = l ^ neg;
+    const uint32_t mh = wave_max_u32(kh);
+    KeyMax r;
+    r.eq_high = __ballot(kh == mh);
+    r.unique = (r.eq_high & (r.eq_high - 1)) == 0;
+    r.mx = 0.0;
+    if (!r.unique) {
+        const uint32_t ml = wave_max_u32(kh == mh ? kl : 0u);
+        const uint32_t back = (mh & 0x80000000u) ? 0u : 0xFFFFFFFFu;
+        r.mx = ccsp_from_bits(((uint64_t)(mh ^ (back | 0x80000000u)) << 32) | (uint64_t)(ml ^ back));
+    }
+    return r;
 }
 
 // the r-th (0-based) set bit of a 128-bit wave-uniform mask (lo = entries 0..63, hi = 64..127):
@@ -519,12 +548,17 @@ __device__ __forceinline__ Pick pick_edge(const double *__restrict__ sqrt_tab, c
         const int j = lane + 64 * h;
         qu[h] = -INFINITY; wv[h] = 0.0; n[h] = 0; ch[h] = 0; mv[h] = 0;
         if (j < K) {
-            const double p = blk_P(b, K)[j];
-            const double w = blk_W(b, K)[j];
+            // the five arrays through scalar base + 32-bit lane offset: the offsets are pinned inside the loop (an empty asm), or their
+            // zero-extensions are hoisted out of it as 64-bit pairs and every load gets a 64-bit vector address computation of its own
+            uint32_t o8 = 8u * (uint32_t)j, o4 = 4u * (uint32_t)j, o2 = 2u * (uint32_t)j;
+            asm volatile("" : "+v"(o8), "+v"(o4), "+v"(o2));
+            const uint8_t *e = b + BLOCK_HDR;
+            const double p = *reinterpret_cast<const double *>(e + o8);
+            const double w = *reinterpret_cast<const double *>(e + 8 * K + o8);
             wv[h] = w;
-            n[h] = blk_N(b, K)[j];
-            ch[h] = blk_child(b, K)[j];
-            mv[h] = blk_mv(b, K)[j];
+            n[h] = *reinterpret_cast<const uint32_t *>(e + 16 * K + o4);
+            ch[h] = *reinterpret_cast<const uint32_t *>(e + 20 * K + o4);
+            mv[h] = *reinterpret_cast<const uint16_t *>(e + 24 * K + o2);
             double U, Q;
             if (RCP) {                                                               // same quotients, fewer instructions
                 const double dn = (double)n[h];
@@ -539,9 +573,18 @@ __device__ __forceinline__ Pick pick_edge(const double *__restrict__ sqrt_tab, c
     }
     // running max with an epsilon tie list (MCTS.py:65-69), closed form:
     // m = first index of the maximum; ties = {m} + {j > m : |QU_j - QU_m| < eps}
-    const double mx = wave_max_f64(WIDE ? (qu[0] > qu[H - 1] ? qu[0] : qu[H - 1]) : qu[0]);
-    const uint64_t eq_lo = __ballot(qu[0] == mx), eq_hi = WIDE ? __ballot(qu[H - 1] == mx) : 0;
-    const int m = (!WIDE || eq_lo) ? ccsp_ctz64(eq_lo) : 64 + ccsp_ctz64(eq_hi);
+    double mx; int m;
+    if (!WIDE) {
+        // the usual node: ONE lane holds the largest high word of the order-preserving key -- that lane is m and its value the maximum
+        // (11 vector instructions fewer than the second reduction over the low words, which runs only when high words tie)
+        const KeyMax km = wave_max_f64_key(qu[0]);
+        if (km.unique) { m = ccsp_ctz64(km.eq_high); mx = ccsp_from_bits(bcast64(ccsp_to_bits(qu[0]), m)); }
+        else { mx = km.mx; m = ccsp_ctz64(__ballot(qu[0] == mx)); }
+    } else {
+        mx = wave_max_f64(qu[0] > qu[H - 1] ? qu[0] : qu[H - 1]);
+        const uint64_t eq_lo = __ballot(qu[0] == mx), eq_hi = __ballot(qu[H - 1] == mx);
+        m = eq_lo ? ccsp_ctz64(eq_lo) : 64 + ccsp_ctz64(eq_hi);
+    }
     uint64_t tie_lo = __ballot(lane > m && fabs(qu[0] - mx) < CCSP_EPSILON);
     uint64_t tie_hi = WIDE ? __ballot(lane + 64 > m && fabs(qu[H - 1] - mx) < CCSP_EPSILON) : 0;
     Pick pk;
@@ -561,9 +604,14 @@ __device__ __forceinline__ Pick pick_edge(const double *__restrict__ sqrt_tab, c
     return pk;
 }
 
+#ifndef CCSP_ADVANCE_DEADLINE_CODE
+#define CCSP_ADVANCE_DEADLINE_CODE 1
+#endif
+// `give_up_at` (ccsp_advance): a value of the 100 MHz clock (its low 32 bits) past which the walk is abandoned at the next level (Leaf.kind 0; nothing has been
+// changed: the caller selects again in its next call); 0 = never
 template <bool RCP, bool REGPATH = RCP, bool SHADOW = false>   // RCP: divisions through a table of reciprocals; REGPATH: the caller keeps the path's first 64 levels in registers; SHADOW: tree reuse (ccsp_advance)
 __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab, const double *rcp, const SimCtx &sl, uint8_t *pool, uint64_t *path, uint32_t sim,
-                                            uint64_t &mypath, double &myW, uint32_t &myN, uint32_t &select_edges) {
+                                            uint64_t &mypath, double &myW, uint32_t &myN, uint32_t &select_edges, uint32_t give_up_at = 0) {
     const int lane = lane_id();
     uint32_t off = 0;
     int K = (int)sl.root_k;
@@ -602,6 +650,7 @@ __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab,
         if ((!REGPATH || level >= 64) && lane == 0) path[level] = entry;   // the fused kernel keeps 64 levels in registers
         level++;
         if (c_sel != CHILD_LEAF && c_sel != CHILD_TERMINAL) {       // descend (MCTS.py:74)
+            if (CCSP_ADVANCE_DEADLINE_CODE && SHADOW && give_up_at != 0 && (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - give_up_at) > 0) { out.kind = 0; out.depth = level; return out; }
             off = (c_sel >> 7) << 3;
             K = (int)(c_sel & 127);
             nsum = n_sel - 1;
@@ -1207,6 +1256,44 @@ __device__ __forceinline__ void store_slot(SlotMem *p, const Slot &s) {
         q[6] = make_ulonglong2(s.hm0, s.hm1);
     }
 }
+// advance_kernel's forms: the record comes in through the SCALAR cache (two s_load_dwordx16: no vector loads, none of the 30
+// v_readfirstlane a per-lane load of wave-uniform data needs -- beside an evaluator launch every vector instruction of a tree wave waits
+// for a gap between MFMAs, scalar ones do not), and only the words a search changes go back.  The record was written by an EARLIER
+// launch (the scalar cache is invalidated when a kernel starts); nothing in the calling kernel may have stored to it before.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+__device__ __forceinline__ Slot load_slot_scalar(const SlotMem *p, uint64_t &w15) {
+    u32x16 a, b;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+    Slot s;
+    s.st.occ0 = pair64(a[0], a[1]); s.st.occ1 = pair64(a[2], a[3]); s.st.a = pair64(a[4], a[5]); s.st.b = pair64(a[6], a[7]);
+    s.game = pair64(a[8], a[9]); s.hgame = pair64(a[10], a[11]); s.index = pair64(a[12], a[13]); s.expansions = pair64(a[14], a[15]);
+    s.ply = b[0]; s.n_hist = b[1]; s.useless = (int32_t)b[2]; s.pool_used = b[3]; s.root_k = b[4]; s.sim = b[5];
+    const uint64_t d = pair64(b[6], b[7]);
+    s.player = (uint32_t)(d & 0xFF); s.status = (uint32_t)((d >> 8) & 0xFF); s.det_tau = (uint32_t)((d >> 16) & 0xFF);
+    s.n_hm = (uint32_t)((d >> 24) & 0xFF); s.progress0 = (uint32_t)((d >> 32) & 0xFF); s.progress1 = (uint32_t)((d >> 40) & 0xFF);
+    s.player_turn = (uint32_t)((d >> 48) & 0xFF); s.opening_left = (uint32_t)((d >> 56) & 0xFF);
+    s.hm0 = pair64(b[8], b[9]); s.hm1 = pair64(b[10], b[11]);
+    w15 = pair64(b[14], b[15]);
+    return s;
+}
+__device__ __forceinline__ void store_slot_search(SlotMem *p, const Slot &s) {      // expansions, pool_used, sim: what a simulation changes
+    if (lane_id() == 0) {
+        p->w[7] = s.expansions;
+        p->w[9] = (uint64_t)(uint32_t)s.useless | ((uint64_t)s.pool_used << 32);
+        p->w[10] = (uint64_t)s.root_k | ((uint64_t)s.sim << 32);
+    }
+}
+__device__ __forceinline__ Pending load_pending_scalar(const Pending *p) {
+    u32x8 a; u32x4 b;
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+    Pending pd;
+    pd.leaf.occ0 = pair64(a[0], a[1]); pd.leaf.occ1 = pair64(a[2], a[3]); pd.leaf.a = pair64(a[4], a[5]); pd.leaf.b = pair64(a[6], a[7]);
+    pd.kind = b[0]; pd.depth = b[1]; pd.link_off = b[2]; pd.leaf_player = b[3];
+    return pd;
+}
 __device__ __forceinline__ Slot empty_slot() {
     Slot s;
     s.st.occ0 = s.st.occ1 = s.st.a = s.st.b = 0; s.game = s.hgame = s.index = s.expansions = 0;
@@ -1569,6 +1656,9 @@ __device__ __forceinline__ void write_w15(const Params &P, int g, uint32_t phase
     if (lane_id() == 0) P.slots[g].w[15] = (uint64_t)phase | ((uint64_t)half << 8) | (1ULL << 9) | ((uint64_t)root_shadow << 32);   // (bit 9: the start delay is spent)
 }
 
+#ifndef CCSP_ADVANCE_PRIO
+#define CCSP_ADVANCE_PRIO 2
+#endif
 __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, int stagger) {
     __shared__ Lds lds;
     const int g = blockIdx.x, lane = lane_id();
@@ -1594,7 +1684,7 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     }
     Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(CCSP_ADVANCE_PRIO);
     load_engine_lines(&lds.T, lane);
     __syncthreads();
     const bool reuse = (flags & CCSP_ADVANCE_REUSE) != 0;
@@ -1666,19 +1756,22 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
 #ifndef CCSP_ADVANCE_WAVES
 #define CCSP_ADVANCE_WAVES 6
 #endif
-__global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params P, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, int budget) {
+template <bool DBG>       // DBG: the per-phase cycle stamps (CCSP_ADVANCE_DEBUG) -- a build of their own: their ten 64-bit sums cost the plain kernel twenty scalar registers
+__global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params P_in_kernarg, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, int budget, int time_cap, int deadline) {
+    // The parameter block is read where it is used, through the kernel-argument segment (scalar loads), instead of by name: named, all of it
+    // is loaded in the first block and what the selection loop does not need is parked in vector-register lanes for the whole call
+    // (v_writelane / v_readlane: vector instructions, which is what a tree wave must not spend beside an evaluator launch).
+    const Params &P = *(const Params *)__builtin_amdgcn_kernarg_segment_ptr();
+    static_assert(offsetof(Params, slots) == 0, "Params is the kernel's first argument");
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_LIGHT];      // the struct without its last member (pi / gam / rcp: never touched here)
     Lds &lds = *reinterpret_cast<Lds *>(lds_raw);
     const int g = blockIdx.x, lane = lane_id();
-    const uint64_t w15 = uni64(P.slots[g].w[15]);
+    uint64_t w15;
+    Slot sl = load_slot_scalar(P.slots + g, w15);
     uint32_t phase = (uint32_t)(w15 & 0xFF);
     const uint32_t half = (uint32_t)((w15 >> 8) & 1), root_shadow = (uint32_t)(w15 >> 32);
     if (phase != 1) return;                               // at a ply boundary: boundary_kernel's business
-    Slot sl = load_slot(P.slots + g);
     if (sl.status != CCSP_ST_RUNNING) return;
-#ifndef CCSP_ADVANCE_PRIO
-#define CCSP_ADVANCE_PRIO 2
-#endif
     __builtin_amdgcn_s_setprio(CCSP_ADVANCE_PRIO);       // beside an evaluator launch: the short tree kernels go first
     load_engine_lines(&lds.T, lane);
     __syncthreads();
@@ -1687,24 +1780,26 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
     const uint8_t *old = (half ? P.pool : P.pool2) + (uint64_t)g * P.pool_stride;
     uint64_t *path = P.path + (uint64_t)g * P.path_stride;
     uint32_t a_exp = 0, a_term = 0, a_sims = 0, a_depth = 0, a_children = 0, a_edges = 0, a_hits = 0, errors = 0;
-    Pending pd;
-    {
-        const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(P.pend + g);
-        const ulonglong2 a = q[0], b = q[1], c = q[2];
-        pd.leaf.occ0 = uni64(a.x); pd.leaf.occ1 = uni64(a.y); pd.leaf.a = uni64(b.x); pd.leaf.b = uni64(b.y);
-        const uint64_t c0 = uni64(c.x), c1 = uni64(c.y);
-        pd.kind = (uint32_t)c0; pd.depth = (uint32_t)(c0 >> 32); pd.link_off = (uint32_t)c1; pd.leaf_player = (uint32_t)(c1 >> 32);
-    }
+    Pending pd = load_pending_scalar(P.pend + g);
     bool answered = pd.kind == 1;                         // the evaluator's answer for the leaf this slot asked about last time
+    // `deadline` (10-ns ticks since the wave began; 0 = none): a wave that has done other work in this call -- the answered leaf's expansion,
+    // evaluator-free simulations -- and is later than that gives its selection up (before it, or between two levels of it) and leaves no
+    // request: one idle evaluator row instead of a launch that waits for its last wave.  A call that BEGINS with the selection never gives up,
+    // so the slot moves on in its next call whatever the deadline.
+    const bool began_with_work = answered;
     uint32_t request = 0;
     int spent = 0;
     // diagnostic (CCSP_ADVANCE_DEBUG): cycles of this wave per phase -- [0] set-up, [1] expansion, [2] backup, [3] selection + shadow,
     // [4] encode + hand-off, [5] whole call, [6] calls, [7] expansions, [8] selections -- summed over the waves into P.dbg
-    const bool dbg = (flags & CCSP_ADVANCE_DEBUG) != 0;
+    constexpr bool dbg = DBG;
     unsigned long long t_exp = 0, t_bak = 0, t_sel = 0, t_enc = 0, n_exp = 0, n_sel = 0, tq = 0;
     const unsigned long long t_begin = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long r_begin = (dbg || time_cap > 0 || deadline > 0) ? __builtin_amdgcn_s_memrealtime() : 0;      // the constant 100 MHz clock (diagnostic: what a tick of s_memtime is worth)
     unsigned long long t_mark = t_begin;
-#define ADV_LAP(acc) do { if (dbg) { __builtin_amdgcn_s_waitcnt(0); tq = __builtin_amdgcn_s_memtime(); acc += tq - t_mark; t_mark = tq; } } while (0)
+#ifndef CCSP_ADVANCE_LAP_WAITS
+#define CCSP_ADVANCE_LAP_WAITS 0      // 1: a phase ends when its memory operations have completed (serialises the wave: 2.4 x slower); 0: when its last instruction has issued
+#endif
+#define ADV_LAP(acc) do { if (dbg) { if (CCSP_ADVANCE_LAP_WAITS) __builtin_amdgcn_s_waitcnt(0); tq = __builtin_amdgcn_s_memtime(); acc += tq - t_mark; t_mark = tq; } } while (0)
     unsigned long long t_setup = 0;
     ADV_LAP(t_setup);
     for (;;) {
@@ -1719,7 +1814,15 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
             mypath = (lane < depth) ? path[lane] : 0;
         } else {
             if (sl.sim >= (uint32_t)P.sims) { phase = 2; break; }      // the search is done: boundary_kernel ends the ply in the next call
-            const bool last = spent >= budget;            // budget spent: one more selection, taken up only if it asks the evaluator
+            // budget spent: one more selection, taken up only if it asks the evaluator.  The budget is a number of simulations AND, past
+            // the first one, a time (`time_cap`, 10-ns ticks since the wave began): a launch lasts as long as its slowest wave, and the
+            // waves that go on through reused positions are the slowest -- a wave that has already been running for longer than the
+            // usual one stops taking them up, a fast one may take up more.  Results do not depend on either.
+            const bool last = spent >= budget ||
+                              (time_cap > 0 && spent > 0 && (long long)(__builtin_amdgcn_s_memrealtime() - r_begin) > (long long)time_cap);
+            // (the low 32 bits of the clock, compared through a signed difference; | 1: zero means "never")
+            const uint32_t give_up_at = (CCSP_ADVANCE_DEADLINE_CODE && deadline > 0 && (began_with_work || spent > 0)) ? (((uint32_t)r_begin + (uint32_t)deadline) | 1u) : 0u;
+            if (give_up_at != 0 && (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - give_up_at) > 0) break;
             SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
             uint32_t edges = 0;
 #ifndef CCSP_ADVANCE_RCP
@@ -1728,8 +1831,9 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
             // the two IEEE divisions per edge and level through the table of reciprocals (read from global memory here: 3.4 KB, cached --
             // the LDS copy the fused kernel keeps would cost this kernel four of its workgroups per CU): 28 vector instructions fewer
             // per edge; beside the evaluator every vector instruction of a tree wave waits for a gap between two MFMAs
-            const Leaf lf = reuse ? wave_select<CCSP_ADVANCE_RCP != 0, false, true>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges)
+            const Leaf lf = reuse ? wave_select<CCSP_ADVANCE_RCP != 0, false, true>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges, give_up_at)
                                   : wave_select<CCSP_ADVANCE_RCP != 0, false, false>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges);
+            if (lf.kind == 0) break;                      // given up between two levels: nothing was changed
             a_sims += 1; a_depth += (uint32_t)lf.depth; a_edges += edges;
             leaf = lf.st; leaf_player = lf.player; depth = lf.depth; link_off = lf.link_off;
             have_stats = true;
@@ -1785,9 +1889,15 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
     if (dbg && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-        atomicAdd(&P.dbg[0], t_setup); atomicAdd(&P.dbg[1], t_exp); atomicAdd(&P.dbg[2], t_bak); atomicAdd(&P.dbg[3], t_sel);
-        atomicAdd(&P.dbg[4], t_enc); atomicAdd(&P.dbg[5], t_end - t_begin); atomicAdd(&P.dbg[6], 1ULL); atomicAdd(&P.dbg[7], n_exp);
-        atomicAdd(&P.dbg[8], n_sel); atomicMax(&P.dbg[9], t_end - t_begin);
+        // per slot, plain read-modify-writes (ten atomics per wave on one cache line made the launch three times as long)
+        unsigned long long *d = P.dbg + (size_t)g * CCSP_DBG_STRIDE;
+        d[0] += t_setup; d[1] += t_exp; d[2] += t_bak; d[3] += t_sel; d[4] += t_enc; d[5] += t_end - t_begin; d[6] += 1ULL; d[7] += n_exp;
+        d[8] += n_sel; if (t_end - t_begin > d[9]) d[9] = t_end - t_begin;
+        d[10] += __builtin_amdgcn_s_memrealtime() - r_begin;
+        const int sb = spent < 3 ? spent : 3;           // [11 .. 14] time of the calls that completed 0 / 1 / 2 / 3+ evaluator-free simulations, [15] their numbers (4 x 16 bits)
+        d[11 + sb] += t_end - t_begin; d[15] += 1ULL << (16 * sb);
+        const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();       // [16 .. 19]: this slot's LAST call -- begin, end (100 MHz clock, the same on every CU), simulations, levels
+        d[16] = r_begin; d[17] = r_end; d[18] = (unsigned long long)spent | ((unsigned long long)request << 32); d[19] = a_depth;
     }
     if (lane == 0) {
         if (request != 1) P.pend[g].kind = 0;             // nothing asked: the search is done, or the budget is spent
@@ -1801,7 +1911,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
         }
     }
     write_w15(P, g, phase, half, root_shadow);
-    store_slot(P.slots + g, sl);
+    store_slot_search(P.slots + g, sl);
 }
 
 // stepped path, phase 5: pi, sampling, move, rules (or the random opening move)
@@ -1972,8 +2082,8 @@ static ccsp_ctx *create_on_device(const ccsp_config *cfg, int *err) {
     CTXALLOC(&P.pool, ctx->pool_bytes);
     CTXALLOC(&P.path, ctx->path_bytes);
     CTXALLOC(&P.counters, CCSP_CNT_COUNT * sizeof(unsigned long long));
-    CTXALLOC(&P.dbg, 64 * sizeof(unsigned long long));
-    CTXCHK(hipMemset(P.dbg, 0, 64 * sizeof(unsigned long long)));
+    CTXALLOC(&P.dbg, (size_t)P.n_slots * CCSP_DBG_STRIDE * sizeof(unsigned long long));
+    CTXCHK(hipMemset(P.dbg, 0, (size_t)P.n_slots * CCSP_DBG_STRIDE * sizeof(unsigned long long)));
     CTXALLOC(&P.stepacc, G * 8 * sizeof(uint32_t));
     CTXALLOC(&P.visit_hist, CCSP_NUM_ACTIONS * sizeof(unsigned long long));
     CTXALLOC(&P.log_count, sizeof(unsigned long long));
@@ -2155,13 +2265,43 @@ int ccsp_debug_read(ccsp_ctx *ctx, unsigned long long *out /* [64] */, int clear
     if (!ctx || !out) return CCSP_EINVAL;
     CTX_ENTER(ctx, nullptr);
     CCSP_HIPCHK(hipDeviceSynchronize());
-    CCSP_HIPCHK(hipMemcpy(out, ctx->P.dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (clear) CCSP_HIPCHK(hipMemset(ctx->P.dbg, 0, 64 * sizeof(unsigned long long)));
+    const size_t n = (size_t)ctx->P.n_slots * CCSP_DBG_STRIDE;
+    std::vector<unsigned long long> all(n);
+    CCSP_HIPCHK(hipMemcpy(all.data(), ctx->P.dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (clear) CCSP_HIPCHK(hipMemset(ctx->P.dbg, 0, n * sizeof(unsigned long long)));
+    for (int i = 0; i < 64; i++) out[i] = 0;
+    for (size_t g = 0; g < (size_t)ctx->P.n_slots; g++) {        // [0..8], [10..14] sums over the slots, [9] the longest call of any slot, [16..19] the numbers packed in [15]
+        const unsigned long long *d = all.data() + g * CCSP_DBG_STRIDE;
+        for (int i = 0; i < 16; i++) {
+            if (i == 9) out[9] = d[9] > out[9] ? d[9] : out[9];
+            else if (i == 15) { for (int k = 0; k < 4; k++) out[16 + k] += (d[15] >> (16 * k)) & 0xFFFF; }
+            else out[i] += d[i];
+        }
+    }
     return CCSP_OK;
 }
 
-static int g_advance_budget = 3;      // measured at 4096 x 400 with good_model.h5: 2 / 3 / 4 -> 16.9 / 17.2 / 16.9 M node-expansions/s
+int ccsp_debug_read_slots(ccsp_ctx *ctx, unsigned long long *out /* [n_slots][CCSP_DEBUG_WORDS_PER_SLOT] */) {
+    if (!ctx || !out) return CCSP_EINVAL;
+    CTX_ENTER(ctx, nullptr);
+    CCSP_HIPCHK(hipDeviceSynchronize());
+    CCSP_HIPCHK(hipMemcpy(out, ctx->P.dbg, (size_t)ctx->P.n_slots * CCSP_DBG_STRIDE * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return CCSP_OK;
+}
+
+// A launch lasts as long as its slowest wave, and the round waits for the launch: in one launch at 4096 x 400 the median wave takes 27 us, the
+// 99th percentile 66, the last 76 (tools/bench_free.py --debug; a wave with three evaluator-free simulations: 49 us on average against 26
+// without).  What trims that tail, measured in steady state on one MI355X with good_model.h5 (M node-expansions/s):
+//   budget 3, no time limits                       18.21
+//   budget 8, time cap 30 / 40 / 50 / 60 / 75 us   18.68 / 19.15 / 19.50 / 19.50 / 19.39    (budget 16: the same)
+//   ... cap 50 + deadline 60 / 70 / 80 / 90 us     19.00 / 19.52 / 19.72 / 19.73            (the deadline's checks cost 2 % of what they win)
+// Neither changes a game: a slot's record depends on the order of ITS simulations only.
+static int g_advance_budget = 8;
+static int g_advance_time_cap = 5000;    // 10-ns ticks; 0 = none
+static int g_advance_deadline = 8000;    // 10-ns ticks; 0 = none
+int ccsp_debug_advance_deadline(int ticks) { const int was = g_advance_deadline; if (ticks >= 0) g_advance_deadline = ticks; return was; }
 int ccsp_debug_advance_budget(int n) { const int was = g_advance_budget; if (n >= 1) g_advance_budget = n; return was; }
+int ccsp_debug_advance_time_cap(int ticks) { const int was = g_advance_time_cap; if (ticks >= 0) g_advance_time_cap = ticks; return was; }
 
 int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream) {
     if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD | CCSP_ADVANCE_STAGGER | CCSP_ADVANCE_DEBUG))) return CCSP_EINVAL;
@@ -2169,7 +2309,10 @@ int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, 
     if ((flags & CCSP_ADVANCE_REUSE) && !ctx->P.pool2) return CCSP_ESTATE;  // ccsp_enable_tree_reuse first (an allocation: not inside a captured graph)
     if (ctx->phase != 0) return CCSP_ESTATE;                                // not in the middle of a lock-step ply
     CTX_ENTER(ctx, stream);
-    hipLaunchKernelGGL(advance_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget);
+    if (flags & CCSP_ADVANCE_DEBUG)
+        hipLaunchKernelGGL(advance_kernel<true>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget, g_advance_time_cap, g_advance_deadline);
+    else
+        hipLaunchKernelGGL(advance_kernel<false>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget, g_advance_time_cap, g_advance_deadline);
     CCSP_HIPCHK(hipGetLastError());
     ctx->opening_plies = -1;
     return CCSP_OK;

@@ -128,6 +128,11 @@ class SelfPlayEngine(object):
         check(self.L.ccsp_debug_read(self.ctx, out.ctypes.data, int(clear)), 'ccsp_debug_read')
         return [int(x) for x in out]
 
+    def debug_read_slots(self):
+        out = np.zeros((self.n_slots, 20), dtype=np.uint64)
+        check(self.L.ccsp_debug_read_slots(self.ctx, out.ctypes.data), 'ccsp_debug_read_slots')
+        return out
+
     def raw_counters(self):
         out = np.zeros(CNT_COUNT, dtype=np.uint64)
         check(self.L.ccsp_read_counters(self.ctx, out.ctypes.data), 'ccsp_read_counters')

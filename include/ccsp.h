@@ -274,11 +274,23 @@ enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2, CCSP_ADVANCE_STAGGER 
 int ccsp_enable_tree_reuse(ccsp_ctx *ctx);
 int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
 int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
-/* evaluator-free simulations (won leaves, reused positions) a slot may complete in ONE ccsp_advance (default 3: bounds the launch's
+/* evaluator-free simulations (won leaves, reused positions) a slot may complete in ONE ccsp_advance (default 8: bounds the launch's
  * length; results do not depend on it; at least 1: a slot must be able to get past a won leaf).  Returns the previous value; n < 1 only reads it. */
 int ccsp_debug_advance_budget(int n);
+/* ... and, past a slot's first such simulation in a call, a time: the slot takes up no further one once `ticks` x 10 ns have passed since its
+ * wave began (a launch lasts as long as its slowest wave).  Default 5000 (50 us); 0 = no cap.  Returns the previous value; ticks < 0 only reads it. */
+int ccsp_debug_advance_time_cap(int ticks);
+/* ... and a deadline for the selection that ends a call: a slot that has done other work in this call (its answered leaf's expansion,
+ * evaluator-free simulations) and is later than `ticks` x 10 ns gives the selection up, before it or between two of its levels, and leaves
+ * no request (one idle evaluator row); it selects again in the next call, which begins with the selection and never gives up.
+ * Default 8000 (80 us); 0 = none. */
+int ccsp_debug_advance_deadline(int ticks);
 /* diagnostic: the cycle sums ccsp_advance keeps under CCSP_ADVANCE_DEBUG (64 words; see advance_kernel); clear != 0 zeroes them */
 int ccsp_debug_read(ccsp_ctx *ctx, unsigned long long *out, int clear);
+/* diagnostic: the same per slot, raw ([n_slots][CCSP_DEBUG_WORDS_PER_SLOT]; words 16-19 = the slot's LAST ccsp_advance: begin and end on
+ * the 100 MHz clock every CU shares, simulations completed, levels walked) -- tools/bench_free.py --debug draws a launch's timeline from it */
+#define CCSP_DEBUG_WORDS_PER_SLOT 20
+int ccsp_debug_read_slots(ccsp_ctx *ctx, unsigned long long *out);
 
 /* ---- evaluator: the policy/value network as one fused kernel (row N1; Model.predict, model.py:21-24) ---- */
 

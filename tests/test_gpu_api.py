@@ -406,22 +406,31 @@ def test_free_running_slots_play_the_lock_step_games(golden_dir):
     cw = b.eng.counters()
     b.close()
     assert any(h is None for h, _ in want) and sum(isinstance(h, list) for h, _ in want) > n // 2 and cw['cache_hits'] == 0
-    was = L.ccsp_debug_advance_budget(-1)
+    was = L.ccsp_debug_advance_budget(-1), L.ccsp_debug_advance_time_cap(-1), L.ccsp_debug_advance_deadline(-1)
+    assert was[0] >= 1 and was[1] > 0 and was[2] > 0          # the defaults: a time cap and a deadline are in force
     try:
-        for budget, reuse, graph in ((4, True, True), (1, True, True), (2, True, False), (64, True, True), (4, False, True)):
+        # ... and whatever the time cap on such simulations and the deadline of a call's closing selection (ticks of 10 ns; 1 = passed at
+        # every check: no second evaluator-free simulation in a call, every selection that follows other work given up; 0 = none)
+        for budget, reuse, graph, cap, deadline in ((4, True, True, 0, 0), (1, True, True, was[1], was[2]), (2, True, False, 0, 1),
+                                                    (64, True, True, 1, 1), (4, False, True, 0, 0), (8, True, True, 300, 500),
+                                                    (64, True, False, 0, 200)):
             L.ccsp_debug_advance_budget(budget)
+            L.ccsp_debug_advance_time_cap(cap)
+            L.ccsp_debug_advance_deadline(deadline)
             b = sp.BatchSelfPlay(m, n_slots=n, sims=sims, seed=seed, first_game=first, max_games=n, log_capacity=n * 600,
                                  free_running=True, reuse=reuse, use_graph=graph)
             got = _records(b.run_to_completion(max_plies=1100))
             c = b.eng.counters()
             b.close()
-            assert got == want, (budget, reuse, graph)
+            assert got == want, (budget, reuse, graph, cap, deadline)
             for k in ('expansions', 'terminal_sims', 'sims', 'plies', 'mcts_plies', 'games_won', 'games_discarded', 'sum_depth', 'sum_children',
                       'select_edges', 'samples', 'errors'):
-                assert c[k] == cw[k], (k, budget, reuse, graph)
+                assert c[k] == cw[k], (k, budget, reuse, graph, cap, deadline)
             assert (c['cache_hits'] > 0.1 * c['expansions']) if reuse else c['cache_hits'] == 0, (c['cache_hits'], c['expansions'])
     finally:
-        L.ccsp_debug_advance_budget(was)
+        L.ccsp_debug_advance_budget(was[0])
+        L.ccsp_debug_advance_time_cap(was[1])
+        L.ccsp_debug_advance_deadline(was[2])
     # two models, randomised starts
     m2 = ResidualCNN()
     m2.load_weights(golden_dir + '/good_model2.h5')
