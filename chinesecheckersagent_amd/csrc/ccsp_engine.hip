@@ -2296,9 +2296,18 @@ int ccsp_debug_read_slots(ccsp_ctx *ctx, unsigned long long *out /* [n_slots][CC
 //   budget 8, time cap 30 / 40 / 50 / 60 / 75 us   18.68 / 19.15 / 19.50 / 19.50 / 19.39    (budget 16: the same)
 //   ... cap 50 + deadline 60 / 70 / 80 / 90 us     19.00 / 19.52 / 19.72 / 19.73            (the deadline's checks cost 2 % of what they win)
 // Neither changes a game: a slot's record depends on the order of ITS simulations only.
+// The two times are those of a batch of more than 1024 slots (an evaluator launch of 118 us beside the call); a smaller batch's evaluator
+// launch is shorter (76 us up to 1024 positions, 47 us up to 512: ccsp_net_forward's workgroup shapes) and the times shrink with it
+// (2048 slots in two half-batches: deadline 50 us 14.62 M, 80 us 14.37 M).
 static int g_advance_budget = 8;
 static int g_advance_time_cap = 5000;    // 10-ns ticks; 0 = none
 static int g_advance_deadline = 8000;    // 10-ns ticks; 0 = none
+static int scaled_ticks(int ticks, int n_slots) {
+    if (ticks <= 0) return 0;
+    const int launch_us = n_slots <= 512 ? 47 : n_slots <= 1024 ? 76 : 120;
+    const long long t = (long long)ticks * launch_us / 120;
+    return (int)(t < 1 ? 1 : t);
+}
 int ccsp_debug_advance_deadline(int ticks) { const int was = g_advance_deadline; if (ticks >= 0) g_advance_deadline = ticks; return was; }
 int ccsp_debug_advance_budget(int n) { const int was = g_advance_budget; if (n >= 1) g_advance_budget = n; return was; }
 int ccsp_debug_advance_time_cap(int ticks) { const int was = g_advance_time_cap; if (ticks >= 0) g_advance_time_cap = ticks; return was; }
@@ -2310,9 +2319,9 @@ int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, 
     if (ctx->phase != 0) return CCSP_ESTATE;                                // not in the middle of a lock-step ply
     CTX_ENTER(ctx, stream);
     if (flags & CCSP_ADVANCE_DEBUG)
-        hipLaunchKernelGGL(advance_kernel<true>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget, g_advance_time_cap, g_advance_deadline);
+        hipLaunchKernelGGL(advance_kernel<true>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget, scaled_ticks(g_advance_time_cap, ctx->P.n_slots), scaled_ticks(g_advance_deadline, ctx->P.n_slots));
     else
-        hipLaunchKernelGGL(advance_kernel<false>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget, g_advance_time_cap, g_advance_deadline);
+        hipLaunchKernelGGL(advance_kernel<false>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget, scaled_ticks(g_advance_time_cap, ctx->P.n_slots), scaled_ticks(g_advance_deadline, ctx->P.n_slots));
     CCSP_HIPCHK(hipGetLastError());
     ctx->opening_plies = -1;
     return CCSP_OK;

@@ -283,7 +283,7 @@ int ccsp_debug_advance_time_cap(int ticks);
 /* ... and a deadline for the selection that ends a call: a slot that has done other work in this call (its answered leaf's expansion,
  * evaluator-free simulations) and is later than `ticks` x 10 ns gives the selection up, before it or between two of its levels, and leaves
  * no request (one idle evaluator row); it selects again in the next call, which begins with the selection and never gives up.
- * Default 8000 (80 us); 0 = none. */
+ * Default 8000 (80 us); 0 = none.  Both times are scaled down for contexts of 1024 slots or fewer (a shorter evaluator launch runs beside the call). */
 int ccsp_debug_advance_deadline(int ticks);
 /* diagnostic: the cycle sums ccsp_advance keeps under CCSP_ADVANCE_DEBUG (64 words; see advance_kernel); clear != 0 zeroes them */
 int ccsp_debug_read(ccsp_ctx *ctx, unsigned long long *out, int clear);

@@ -52,10 +52,10 @@ for kind, budget, *rest in cases:
         run.play_ply()
     run.drain()
     torch.cuda.synchronize()
-    raw0 = [sum(x) for x in zip(*[b.eng.raw_counters() for b in run.b.parts])] if a.debug else None
+    raw0 = [sum(x) for x in zip(*[b.eng.raw_counters() for b in getattr(run.b, 'parts', [run.b])])] if a.debug else None
     if a.debug:
-        [b.eng.debug_read(True) for b in run.b.parts]
-    for b_ in run.b.parts:
+        [b.eng.debug_read(True) for b in getattr(run.b, 'parts', [run.b])]
+    for b_ in getattr(run.b, 'parts', [run.b]):
         b_.net_events = []
     c0 = run.counters(); t0 = time.time()
     for _ in range(a.plies):
@@ -64,7 +64,7 @@ for kind, budget, *rest in cases:
     dt = time.time() - t0
     c1 = run.counters()
     run.drain()
-    evs = [ev for b_ in run.b.parts for ev in (b_.net_events or [])]
+    evs = [ev for b_ in getattr(run.b, 'parts', [run.b]) for ev in (b_.net_events or [])]
     if evs:
         nets = sorted(e[0].elapsed_time(e[1]) for e in evs); trees = sorted(e[1].elapsed_time(e[2]) for e in evs)
         print('in situ (uncaptured rounds, %d samples): net median %.1f us (min %.1f max %.1f), tree kernels median %.1f us (min %.1f max %.1f)' % (len(evs), nets[len(nets)//2]*1e3, nets[0]*1e3, nets[-1]*1e3, trees[len(trees)//2]*1e3, trees[0]*1e3, trees[-1]*1e3), flush=True)
@@ -75,10 +75,10 @@ for kind, budget, *rest in cases:
                           plies_per_slot_per_play_ply=d['mcts_plies'] / a.plies / a.games, useful_eval_share=(d['expansions'] - d['cache_hits']) / evals,
                           games_per_s=(d['games_won'] + d['games_discarded']) / dt, errors=c1['errors'])), flush=True)
     if a.debug:
-        raw1 = [sum(x) for x in zip(*[b.eng.raw_counters() for b in run.b.parts])]
+        raw1 = [sum(x) for x in zip(*[b.eng.raw_counters() for b in getattr(run.b, 'parts', [run.b])])]
         calls = a.plies * (a.sims + 1) * a.games
         import numpy as np
-        for pi_, b_ in enumerate(run.b.parts):          # the LAST advance launch of each half-batch: when its waves began and ended (100 MHz clock)
+        for pi_, b_ in enumerate(getattr(run.b, 'parts', [run.b])):          # the LAST advance launch of each half-batch: when its waves began and ended (100 MHz clock)
             sl_ = b_.eng.debug_read_slots()
             ok = sl_[:, 17] > 0
             if ok.sum() < 16:
@@ -96,7 +96,7 @@ for kind, budget, *rest in cases:
             print('half %d, last launch, %d waves: begin p50 %.1f p90 %.1f p99 %.1f max %.1f us | end p50 %.1f p90 %.1f p99 %.1f max %.1f us | own time p50 %.1f p90 %.1f p99 %.1f max %.1f us'
                   % (pi_, len(beg), q(beg, .5), q(beg, .9), q(beg, .99), beg.max(), q(end, .5), q(end, .9), q(end, .99), end.max(),
                      q(end - beg, .5), q(end - beg, .9), q(end - beg, .99), (end - beg).max()), flush=True)
-        dg = [sum(x) for x in zip(*[b.eng.debug_read(True) for b in run.b.parts])]
+        dg = [sum(x) for x in zip(*[b.eng.debug_read(True) for b in getattr(run.b, 'parts', [run.b])])]
         if dg[6]:
             tick = dg[10] * 1e-2 / max(dg[5], 1)      # microseconds per s_memtime tick, from s_memrealtime (100 MHz) over the same calls
             print('advance_kernel per call and wave (us): setup %.1f  expansion %.1f  backup %.1f  selection %.1f  encode %.1f  total %.1f (max %.1f); per call %.2f expansions, %.2f selections' % tuple([dg[i] / dg[6] * tick for i in (0, 1, 2, 3, 4, 5)] + [dg[9] * tick, dg[7] / dg[6], dg[8] / dg[6]]), flush=True)
