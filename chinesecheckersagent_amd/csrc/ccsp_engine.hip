@@ -1650,8 +1650,9 @@ __device__ __forceinline__ int wave_copy_block(SimCtx &sl, uint8_t *pool, const 
 // bits 32-63 = offset / 8, in the OTHER pool, of the block of the current ply's root position (0 = none).  Pending.kind: 0 no request,
 // 1 a leaf, 3 the root.
 // `budget`: simulations a slot may complete without the evaluator (won leaves, reused positions) in one launch; with the budget
-// spent a slot selects once more and leaves its request if that leaf needs the evaluator -- otherwise it returns without one (its row
-// of the next evaluator launch is idle) and selects the same leaf again in the next call.  Bounds the launch's length.
+// spent a slot selects once more and leaves its request if that leaf needs the evaluator -- otherwise it completes that one
+// simulation too (the walk is done) and returns without a request (its row of the next evaluator launch is idle).  With `time_cap`
+// and `deadline` (below) it bounds the launch's length.
 __device__ __forceinline__ void write_w15(const Params &P, int g, uint32_t phase, uint32_t half, uint32_t root_shadow) {
     if (lane_id() == 0) P.slots[g].w[15] = (uint64_t)phase | ((uint64_t)half << 8) | (1ULL << 9) | ((uint64_t)root_shadow << 32);   // (bit 9: the start delay is spent)
 }
@@ -1805,7 +1806,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
     for (;;) {
         ccsp_sr leaf; int leaf_player, depth; uint32_t link_off;
         uint64_t mypath = 0; double myW = 0.0; uint32_t myN = 0;
-        bool terminal = false, have_stats = false;
+        bool terminal = false, have_stats = false, stop_after = false;
         EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = 0.0f; ev.p_edges = nullptr; ev.shadow = 0;
         if (answered) {                                   // expansion with (p, v) + backup (expand_backup_core)
             answered = false;
@@ -1814,7 +1815,8 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
             mypath = (lane < depth) ? path[lane] : 0;
         } else {
             if (sl.sim >= (uint32_t)P.sims) { phase = 2; break; }      // the search is done: boundary_kernel ends the ply in the next call
-            // budget spent: one more selection, taken up only if it asks the evaluator.  The budget is a number of simulations AND, past
+            // budget spent: one more selection -- its leaf's planes go out if it asks the evaluator; a won or reused leaf is still backed up
+            // (the walk to it is the expensive part and is done), and the call ends there.  The budget is a number of simulations AND, past
             // the first one, a time (`time_cap`, 10-ns ticks since the wave began): a launch lasts as long as its slowest wave, and the
             // waves that go on through reused positions are the slowest -- a wave that has already been running for longer than the
             // usual one stops taking them up, a fast one may take up more.  Results do not depend on either.
@@ -1839,7 +1841,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
             have_stats = true;
             n_sel += 1;
             if (lf.kind == 2) {                           // a won leaf: backed up at once (MCTS.py:81-90)
-                if (last) { a_sims -= 1; a_depth -= (uint32_t)lf.depth; a_edges -= edges; break; }   // (selected again in the next call)
+                stop_after = last;                        // budget spent: this simulation is still completed (its selection is done), nothing after it
                 terminal = true; a_term += 1;
             } else {
                 uint32_t shadow = 0;
@@ -1861,7 +1863,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
                     ADV_LAP(t_enc);
                     break;
                 }
-                if (last) { a_sims -= 1; a_depth -= (uint32_t)lf.depth; a_edges -= edges; break; }   // (no request: this slot's row of the next evaluator launch is idle)
+                stop_after = last;                        // (no request: this slot's row of the next evaluator launch is idle)
                 const uint8_t *ob = old + ((uint64_t)shadow << 3);      // expanded there: the evaluator's answer is in that block
                 ev.kind = CCSP_EVAL_CACHED; ev.v_ext = reinterpret_cast<const float *>(ob + 32)[3]; ev.shadow = shadow;
                 a_hits += 1;
@@ -1885,6 +1887,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
         sl.sim += 1;
         __syncthreads();                                  // this simulation's stores before the next one's loads
         ADV_LAP(t_bak);
+        if (stop_after) break;
     }
     if (dbg && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);

@@ -274,7 +274,8 @@ enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2, CCSP_ADVANCE_STAGGER 
 int ccsp_enable_tree_reuse(ccsp_ctx *ctx);
 int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
 int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
-/* evaluator-free simulations (won leaves, reused positions) a slot may complete in ONE ccsp_advance (default 8: bounds the launch's
+/* evaluator-free simulations (won leaves, reused positions) a slot takes up in ONE ccsp_advance before the selection that ends the call
+ * (default 8; if that selection too ends on such a leaf the simulation is completed and the call ends without a request: bounds the launch's
  * length; results do not depend on it; at least 1: a slot must be able to get past a won leaf).  Returns the previous value; n < 1 only reads it. */
 int ccsp_debug_advance_budget(int n);
 /* ... and, past a slot's first such simulation in a call, a time: the slot takes up no further one once `ticks` x 10 ns have passed since its
