@@ -431,6 +431,18 @@ def test_free_running_slots_play_the_lock_step_games(golden_dir):
         L.ccsp_debug_advance_budget(was[0])
         L.ccsp_debug_advance_time_cap(was[1])
         L.ccsp_debug_advance_deadline(was[2])
+    # the diagnostic build of the kernel (per-phase stamps, tools/bench_free.py --debug) plays the same games and accounts for every call
+    sp.BatchSelfPlay.DEBUG = True
+    try:
+        b = sp.BatchSelfPlay(m, n_slots=n, sims=sims, seed=seed, first_game=first, max_games=n, log_capacity=n * 600, free_running=True, reuse=True)
+        got = _records(b.run_to_completion(max_plies=1100))
+        dg, per_slot = b.eng.debug_read(clear=False), b.eng.debug_read_slots()
+        b.close()
+    finally:
+        sp.BatchSelfPlay.DEBUG = False
+    assert got == want
+    assert dg[6] > 0 and dg[6] == int(per_slot[:, 6].sum()) and dg[16] + dg[17] + dg[18] + dg[19] == dg[6]      # calls = calls by simulations completed
+    assert dg[7] >= cw['expansions'] - n * 200 and int(per_slot[:, 17].max()) > int(per_slot[:, 16].min())          # expansions seen; begin < end on the shared clock
     # two models, randomised starts
     m2 = ResidualCNN()
     m2.load_weights(golden_dir + '/good_model2.h5')
