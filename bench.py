@@ -258,8 +258,12 @@ def config3(args, torch, rank, world, local, barrier):
     sink = sp.TrainDataSink()
     sink.discard = True
     # the id budget is never the limit: every slot can restart 64 times
+    # the slots' first games begin spread over the untimed plies (all but the last twelve of them: every slot is playing well before the
+    # warm-up) instead of together: the timed window then sees games END at the long-run rate wherever it sits, not the swell of a first
+    # cohort that began together and ends together one mean game length later
+    span = max(0, args.spread_plies - 12) * (S + 1)
     run = sp.SelfPlayRun(model, n_games=G * 64, sims=S, seed=SEED, first_game=rank, game_stride=world, device=local, max_slots=G,
-                         harvest_every=args.harvest_every, keep_records=False, sink=sink)
+                         harvest_every=args.harvest_every, keep_records=False, sink=sink, stagger_span=span or None)
     out_dir = tempfile.mkdtemp(prefix='ccsp-bench-')
     try:
         for _ in range(args.spread_plies + W):          # untimed: the first cohort of games spreads out, then the W warm-up steps

@@ -81,6 +81,7 @@ _SIGS = {
     'ccsp_enable_tree_reuse': (C.c_int, [_VP]),
     'ccsp_advance': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
     'ccsp_boundary': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
+    'ccsp_set_stagger_span': (C.c_int, [_VP, C.c_int]),
     'ccsp_debug_advance_budget': (C.c_int, [C.c_int]),
     'ccsp_debug_advance_time_cap': (C.c_int, [C.c_int]),
     'ccsp_debug_advance_deadline': (C.c_int, [C.c_int]),

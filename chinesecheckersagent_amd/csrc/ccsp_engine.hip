@@ -1986,6 +1986,7 @@ struct ccsp_ctx {
     void *sqrt_tab, *pow_tab, *rcp_tab;
     uint64_t pool_bytes, path_bytes;
     int phase;                     // stepped path sequencing: 0 idle, 1 begun, 2 root expanded, 3 selected
+    int stagger_span;              // CCSP_ADVANCE_STAGGER: ccsp_boundary calls over which the slots' first games begin (0 = cfg.sims)
     int opening_plies;             // fused plies played since ccsp_reset while EVERY slot is still in its random opening
                                    // (all games start together); -1 once that is no longer known
 };
@@ -2264,6 +2265,12 @@ int ccsp_enable_tree_reuse(ccsp_ctx *ctx) {
     return CCSP_OK;
 }
 
+int ccsp_set_stagger_span(ccsp_ctx *ctx, int boundary_calls) {
+    if (!ctx || boundary_calls < 0 || boundary_calls > 65535) return CCSP_EINVAL;      // (a slot's countdown is 16 bits of its word 15)
+    ctx->stagger_span = boundary_calls;
+    return CCSP_OK;
+}
+
 int ccsp_debug_read(ccsp_ctx *ctx, unsigned long long *out /* [64] */, int clear) {
     if (!ctx || !out) return CCSP_EINVAL;
     CTX_ENTER(ctx, nullptr);
@@ -2337,7 +2344,7 @@ int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes,
     if (ctx->phase != 0) return CCSP_ESTATE;
     CTX_ENTER(ctx, stream);
     hipLaunchKernelGGL(boundary_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags,
-                       (flags & CCSP_ADVANCE_STAGGER) ? ctx->cfg.sims : 0);
+                       (flags & CCSP_ADVANCE_STAGGER) ? (ctx->stagger_span > 0 ? ctx->stagger_span : ctx->cfg.sims) : 0);
     CCSP_HIPCHK(hipGetLastError());
     ctx->opening_plies = -1;
     return CCSP_OK;

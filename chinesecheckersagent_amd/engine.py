@@ -98,6 +98,10 @@ class SelfPlayEngine(object):
         """the second tree pool ccsp_advance(reuse=True) needs (an allocation: call it before capturing a graph)"""
         check(self.L.ccsp_enable_tree_reuse(self.ctx), 'ccsp_enable_tree_reuse')
 
+    def set_stagger_span(self, boundary_calls):
+        """boundary(stagger=True): the number of boundary calls over which the slots' first games begin (default: `sims`)"""
+        check(self.L.ccsp_set_stagger_span(self.ctx, int(min(boundary_calls, 65535))), 'ccsp_set_stagger_span')
+
     def advance(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stream=None, debug=False):
         """slots in a search: take the answer (p, v) to the leaf they asked about, go on to their next request (planes out)"""
         self._check_pv(p, v)

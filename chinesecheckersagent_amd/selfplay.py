@@ -100,7 +100,7 @@ class BatchSelfPlay(object):
 
     def __init__(self, model1, model2=None, n_slots=1, sims=MCTS_SIMULATIONS, seed=None, first_game=0, game_stride=1,
                  max_games=None, randomised=False, auto_restart=False, device=0, log_capacity=None, use_graph=True,
-                 free_running=False, reuse=None, log_guard=False, stagger=False):
+                 free_running=False, reuse=None, log_guard=False, stagger=False, stagger_span=None):
         import torch
         self.torch = torch
         self.m1 = _batched(model1)
@@ -123,6 +123,10 @@ class BatchSelfPlay(object):
             raise ValueError('tree reuse needs ONE model: the previous ply of a two-model game was searched with the other one (selfplay.py:30,59)')
         self.log_guard = bool(log_guard)
         self.stagger = bool(stagger)
+        if self.stagger and stagger_span:                  # rounds over which the slots' FIRST games begin (default: one ply's worth); a span
+            # of a whole game's worth of rounds puts a restarting run into its steady state -- games ending at an even rate -- from the
+            # moment the last slot has started, instead of after several generations of games that began together
+            self.eng.set_stagger_span(max(1, int(stagger_span) // (self.BOUNDARY_EVERY if n_slots >= 1024 else 1)))
         self.steps = 0                                     # free-running: [net -> advance] steps taken
         if self.free_running:
             if self.reuse:
@@ -603,7 +607,7 @@ class SelfPlayRun(object):
 
     def __init__(self, model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False, first_game=0,
                  game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY, use_graph=True, keep_records=True,
-                 sink=None, n_parts=None, free_running=None, reuse=None):
+                 sink=None, n_parts=None, free_running=None, reuse=None, stagger_span=None):
         tune_host_allocator()
         _lib.prefer_blocking_sync()                        # (effective when the process has not touched the GPU yet)
         n_games = int(n_games)
@@ -623,7 +627,7 @@ class SelfPlayRun(object):
         if free_running and hasattr(_batched(model1), 'model'):
             # slots run at their own pace (BatchSelfPlay): between two harvests a slot plays up to ~1.5 plies per `play_ply`; a slot that
             # could find the log full waits for the harvest (log_guard) instead of losing a row
-            kw.update(free_running=True, reuse=reuse, log_guard=True, stagger=n_games > n_slots)      # (restarting slots: a long run)
+            kw.update(free_running=True, reuse=reuse, log_guard=True, stagger=n_games > n_slots, stagger_span=stagger_span)      # (restarting slots: a long run)
             cap = n_slots * (2 * self.harvest_every + 2)
         self.free_running = bool(kw.get('free_running'))
         if n_parts > 1:

@@ -272,6 +272,10 @@ int ccsp_ply_end(ccsp_ctx *ctx, void *stream);
  */
 enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2, CCSP_ADVANCE_STAGGER = 4, CCSP_ADVANCE_DEBUG = 8 /* diagnostic tallies in counters 12-14 */ };
 int ccsp_enable_tree_reuse(ccsp_ctx *ctx);
+/* CCSP_ADVANCE_STAGGER: the number of ccsp_boundary calls over which the slots' first games begin (0 = the default, `sims`; at most 65535).
+ * A span of a whole game's worth of calls puts a restarting run into its steady state -- games ending at an even rate -- as soon as the last
+ * slot has started.  Call it before the first ccsp_boundary. */
+int ccsp_set_stagger_span(ccsp_ctx *ctx, int boundary_calls);
 int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
 int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
 /* evaluator-free simulations (won leaves, reused positions) a slot takes up in ONE ccsp_advance before the selection that ends the call
