@@ -431,6 +431,12 @@ def test_free_running_slots_play_the_lock_step_games(golden_dir):
         L.ccsp_debug_advance_budget(was[0])
         L.ccsp_debug_advance_time_cap(was[1])
         L.ccsp_debug_advance_deadline(was[2])
+    # the slots' first games begin spread over 37 rounds (CCSP_ADVANCE_STAGGER + ccsp_set_stagger_span): the same games
+    b = sp.BatchSelfPlay(m, n_slots=n, sims=sims, seed=seed, first_game=first, max_games=n, log_capacity=n * 600, free_running=True, reuse=True,
+                         stagger=True, stagger_span=37)
+    got = _records(b.run_to_completion(max_plies=1100))
+    b.close()
+    assert got == want
     # the diagnostic build of the kernel (per-phase stamps, tools/bench_free.py --debug) plays the same games and accounts for every call
     sp.BatchSelfPlay.DEBUG = True
     try:
