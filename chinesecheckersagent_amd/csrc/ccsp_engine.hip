@@ -1803,79 +1803,95 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
 #define ADV_LAP(acc) do { if (dbg) { if (CCSP_ADVANCE_LAP_WAITS) __builtin_amdgcn_s_waitcnt(0); tq = __builtin_amdgcn_s_memtime(); acc += tq - t_mark; t_mark = tq; } } while (0)
     unsigned long long t_setup = 0;
     ADV_LAP(t_setup);
+    // (1) the leaf this slot asked about last time: expansion with the evaluator's (p, v) + backup (expand_backup_core) -- once per call and
+    // AHEAD of the loop, like the plane encoder behind it: the move generator's and the encoder's per-lane constants are then not alive across
+    // the selection loop (inside it they were hoisted to the top of the kernel and spilled to scratch: on gfx950 every reload's wait also
+    // waits for all stores issued before it, and every scratch dword is four cache lines of traffic beside the evaluator)
+    if (answered) {
+        const ccsp_sr leaf = pd.leaf; const int leaf_player = (int)pd.leaf_player, depth = (int)pd.depth; const uint32_t link_off = pd.link_off;
+        EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = v[g]; ev.p_edges = nullptr; ev.shadow = 0;
+        const uint64_t mypath = (lane < depth) ? path[lane] : 0;
+        SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
+        uint32_t noff;
+        const int k = wave_expand(lds, cx, pool, leaf, leaf_player, ev, 0, false, noff);
+        sl.pool_used = cx.pool_used;
+        if (k > 0 && lane == 0) *reinterpret_cast<uint32_t *>(pool + link_off) = ((noff >> 3) << 7) | (uint32_t)k;
+        a_exp += 1; a_children += (uint32_t)k; sl.expansions += 1;
+        __syncthreads();
+        n_exp += 1;
+        ADV_LAP(t_exp);
+        wave_backup(pool, path, mypath, 0.0, 0u, false, depth, false, ev.v_ext);
+        sl.sim += 1;
+        __syncthreads();                                  // this simulation's stores before the next one's loads
+        ADV_LAP(t_bak);
+    }
+    // (2) selection -- and on through won leaves and reused positions -- until a leaf needs the evaluator or the call's budget is spent
+    ccsp_sr req_leaf; int req_player = 0;
+    req_leaf.occ0 = req_leaf.occ1 = req_leaf.a = req_leaf.b = 0;
     for (;;) {
         ccsp_sr leaf; int leaf_player, depth; uint32_t link_off;
         uint64_t mypath = 0; double myW = 0.0; uint32_t myN = 0;
         bool terminal = false, have_stats = false, stop_after = false;
-        EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = 0.0f; ev.p_edges = nullptr; ev.shadow = 0;
-        if (answered) {                                   // expansion with (p, v) + backup (expand_backup_core)
-            answered = false;
-            leaf = pd.leaf; leaf_player = (int)pd.leaf_player; depth = (int)pd.depth; link_off = pd.link_off;
-            ev.v_ext = v[g];
-            mypath = (lane < depth) ? path[lane] : 0;
-        } else {
-            if (sl.sim >= (uint32_t)P.sims) { phase = 2; break; }      // the search is done: boundary_kernel ends the ply in the next call
-            // budget spent: one more selection -- its leaf's planes go out if it asks the evaluator; a won or reused leaf is still backed up
-            // (the walk to it is the expensive part and is done), and the call ends there.  The budget is a number of simulations AND, past
-            // the first one, a time (`time_cap`, 10-ns ticks since the wave began): a launch lasts as long as its slowest wave, and the
-            // waves that go on through reused positions are the slowest -- a wave that has already been running for longer than the
-            // usual one stops taking them up, a fast one may take up more.  Results do not depend on either.
-            const bool last = spent >= budget ||
-                              (time_cap > 0 && spent > 0 && (long long)(__builtin_amdgcn_s_memrealtime() - r_begin) > (long long)time_cap);
-            // (the low 32 bits of the clock, compared through a signed difference; | 1: zero means "never")
-            const uint32_t give_up_at = (CCSP_ADVANCE_DEADLINE_CODE && deadline > 0 && (began_with_work || spent > 0)) ? (((uint32_t)r_begin + (uint32_t)deadline) | 1u) : 0u;
-            if (give_up_at != 0 && (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - give_up_at) > 0) break;
-            SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
-            uint32_t edges = 0;
+        EvalCtx ev; ev.kind = CCSP_EVAL_CACHED; ev.p_row = nullptr; ev.v_ext = 0.0f; ev.p_edges = nullptr; ev.shadow = 0;
+        if (sl.sim >= (uint32_t)P.sims) { phase = 2; break; }      // the search is done: boundary_kernel ends the ply in the next call
+        // budget spent: one more selection -- its leaf's planes go out if it asks the evaluator; a won or reused leaf is still backed up
+        // (the walk to it is the expensive part and is done), and the call ends there.  The budget is a number of simulations AND, past
+        // the first one, a time (`time_cap`, 10-ns ticks since the wave began): a launch lasts as long as its slowest wave, and the
+        // waves that go on through reused positions are the slowest -- a wave that has already been running for longer than the
+        // usual one stops taking them up, a fast one may take up more.  Results do not depend on either.
+        const bool last = spent >= budget ||
+                          (time_cap > 0 && spent > 0 && (long long)(__builtin_amdgcn_s_memrealtime() - r_begin) > (long long)time_cap);
+        // (the low 32 bits of the clock, compared through a signed difference; | 1: zero means "never")
+        const uint32_t give_up_at = (CCSP_ADVANCE_DEADLINE_CODE && deadline > 0 && (began_with_work || spent > 0)) ? (((uint32_t)r_begin + (uint32_t)deadline) | 1u) : 0u;
+        if (give_up_at != 0 && (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - give_up_at) > 0) break;
+        SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
+        uint32_t edges = 0;
 #ifndef CCSP_ADVANCE_RCP
 #define CCSP_ADVANCE_RCP 1
 #endif
-            // the two IEEE divisions per edge and level through the table of reciprocals (read from global memory here: 3.4 KB, cached --
-            // the LDS copy the fused kernel keeps would cost this kernel four of its workgroups per CU): 28 vector instructions fewer
-            // per edge; beside the evaluator every vector instruction of a tree wave waits for a gap between two MFMAs
-            const Leaf lf = reuse ? wave_select<CCSP_ADVANCE_RCP != 0, false, true>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges, give_up_at)
-                                  : wave_select<CCSP_ADVANCE_RCP != 0, false, false>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges);
-            if (lf.kind == 0) break;                      // given up between two levels: nothing was changed
-            a_sims += 1; a_depth += (uint32_t)lf.depth; a_edges += edges;
-            leaf = lf.st; leaf_player = lf.player; depth = lf.depth; link_off = lf.link_off;
-            have_stats = true;
-            n_sel += 1;
-            if (lf.kind == 2) {                           // a won leaf: backed up at once (MCTS.py:81-90)
-                stop_after = last;                        // budget spent: this simulation is still completed (its selection is done), nothing after it
-                terminal = true; a_term += 1;
-            } else {
-                uint32_t shadow = 0;
-                if (reuse && lf.parent_shadow != 0) {     // the leaf's position in the previous ply's tree, through its parent's block there
-                    const uint8_t *opb = old + ((uint64_t)lf.parent_shadow << 3);
-                    const uint32_t cw = uni32(*reinterpret_cast<const uint32_t *>(opb + BLOCK_HDR + 20 * lf.parent_k + 4 * lf.sel));
-                    if (cw != CHILD_LEAF && cw != CHILD_TERMINAL) shadow = cw >> 7;
-                }
-                if (shadow == 0) {                        // the evaluator is needed: leaf planes out, the hand-off record for the next call
-                    if (lane == 0) {
-                        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(P.pend + g);
-                        q[0] = make_ulonglong2(leaf.occ0, leaf.occ1);
-                        q[1] = make_ulonglong2(leaf.a, leaf.b);
-                        q[2] = make_ulonglong2(1ULL | ((uint64_t)(uint32_t)depth << 32), (uint64_t)link_off | ((uint64_t)(uint32_t)leaf_player << 32));
-                    }
-                    ADV_LAP(t_sel);
-                    wave_encode(lds, leaf, leaf_player, planes + (uint64_t)g * CCSP_PLANES);
-                    request = 1;
-                    ADV_LAP(t_enc);
-                    break;
-                }
-                stop_after = last;                        // (no request: this slot's row of the next evaluator launch is idle)
-                const uint8_t *ob = old + ((uint64_t)shadow << 3);      // expanded there: the evaluator's answer is in that block
-                ev.kind = CCSP_EVAL_CACHED; ev.v_ext = reinterpret_cast<const float *>(ob + 32)[3]; ev.shadow = shadow;
-                a_hits += 1;
+        // the two IEEE divisions per edge and level through the table of reciprocals (read from global memory here: 3.4 KB, cached --
+        // the LDS copy the fused kernel keeps would cost this kernel four of its workgroups per CU): 28 vector instructions fewer
+        // per edge; beside the evaluator every vector instruction of a tree wave waits for a gap between two MFMAs
+        const Leaf lf = reuse ? wave_select<CCSP_ADVANCE_RCP != 0, false, true>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges, give_up_at)
+                              : wave_select<CCSP_ADVANCE_RCP != 0, false, false>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges);
+        if (lf.kind == 0) break;                      // given up between two levels: nothing was changed
+        a_sims += 1; a_depth += (uint32_t)lf.depth; a_edges += edges;
+        leaf = lf.st; leaf_player = lf.player; depth = lf.depth; link_off = lf.link_off;
+        have_stats = true;
+        n_sel += 1;
+        if (lf.kind == 2) {                           // a won leaf: backed up at once (MCTS.py:81-90)
+            stop_after = last;                        // budget spent: this simulation is still completed (its selection is done), nothing after it
+            terminal = true; a_term += 1;
+        } else {
+            uint32_t shadow = 0;
+            if (reuse && lf.parent_shadow != 0) {     // the leaf's position in the previous ply's tree, through its parent's block there
+                const uint8_t *opb = old + ((uint64_t)lf.parent_shadow << 3);
+                const uint32_t cw = uni32(*reinterpret_cast<const uint32_t *>(opb + BLOCK_HDR + 20 * lf.parent_k + 4 * lf.sel));
+                if (cw != CHILD_LEAF && cw != CHILD_TERMINAL) shadow = cw >> 7;
             }
-            spent += 1;
-            ADV_LAP(t_sel);
+            if (shadow == 0) {                        // the evaluator is needed: the hand-off record for the next call; the leaf's planes go out behind the loop
+                if (lane == 0) {
+                    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(P.pend + g);
+                    q[0] = make_ulonglong2(leaf.occ0, leaf.occ1);
+                    q[1] = make_ulonglong2(leaf.a, leaf.b);
+                    q[2] = make_ulonglong2(1ULL | ((uint64_t)(uint32_t)depth << 32), (uint64_t)link_off | ((uint64_t)(uint32_t)leaf_player << 32));
+                }
+                ADV_LAP(t_sel);
+                req_leaf = leaf; req_player = leaf_player;
+                request = 1;
+                break;
+            }
+            stop_after = last;                        // (no request: this slot's row of the next evaluator launch is idle)
+            const uint8_t *ob = old + ((uint64_t)shadow << 3);      // expanded there: the evaluator's answer is in that block
+            ev.kind = CCSP_EVAL_CACHED; ev.v_ext = reinterpret_cast<const float *>(ob + 32)[3]; ev.shadow = shadow;
+            a_hits += 1;
         }
-        if (!terminal) {
+        spent += 1;
+        ADV_LAP(t_sel);
+        if (!terminal) {                                  // a reused position: its block of the previous ply's tree, re-created in this one
             SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
             uint32_t noff;
-            const int k = ev.kind == CCSP_EVAL_CACHED ? wave_copy_block(cx, pool, old + ((uint64_t)ev.shadow << 3), ev.shadow, noff)
-                                                      : wave_expand(lds, cx, pool, leaf, leaf_player, ev, 0, false, noff);
+            const int k = wave_copy_block(cx, pool, old + ((uint64_t)ev.shadow << 3), ev.shadow, noff);
             sl.pool_used = cx.pool_used;
             if (k > 0 && lane == 0) *reinterpret_cast<uint32_t *>(pool + link_off) = ((noff >> 3) << 7) | (uint32_t)k;
             a_exp += 1; a_children += (uint32_t)k; sl.expansions += 1;
@@ -1888,6 +1904,11 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
         __syncthreads();                                  // this simulation's stores before the next one's loads
         ADV_LAP(t_bak);
         if (stop_after) break;
+    }
+    // (3) the request's planes
+    if (request == 1) {
+        wave_encode(lds, req_leaf, req_player, planes + (uint64_t)g * CCSP_PLANES);
+        ADV_LAP(t_enc);
     }
     if (dbg && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
