@@ -647,7 +647,7 @@ __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab,
         }
         const uint64_t entry = path_entry(off >> 3, K, sel);
         if (level < 64) { if (lane == level) { mypath = entry; myW = ccsp_from_bits(w_sel); myN = n_sel; } }   // backup needs no reload
-        if ((!REGPATH || level >= 64) && lane == 0) path[level] = entry;   // the fused kernel keeps 64 levels in registers
+        if (level >= 64 && lane == 0) path[level] = entry;                 // (the first 64 levels: in `mypath`; written out below where the caller does not keep them)
         level++;
         if (c_sel != CHILD_LEAF && c_sel != CHILD_TERMINAL) {       // descend (MCTS.py:74)
             if (CCSP_ADVANCE_DEADLINE_CODE && SHADOW && give_up_at != 0 && (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - give_up_at) > 0) { out.kind = 0; out.depth = level; return out; }
@@ -658,6 +658,9 @@ __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab,
             continue;
         }
         out.depth = level;
+        // the path for the kernel (or call) that backs this leaf up: ONE store of the lanes' entries instead of one per level from lane 0 -- a
+        // store between two levels' loads makes the next level's wait (the counter runs in order) wait for the store's acknowledgement too
+        if (!REGPATH && lane < (level < 64 ? level : 64)) path[lane] = mypath;
         out.parent_shadow = hdr_shadow; out.parent_k = K; out.sel = sel;
         out.link_off = off + BLOCK_HDR + 20 * K + 4 * sel;
         out.player = 3 - player;
@@ -1774,8 +1777,6 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
     if (phase != 1) return;                               // at a ply boundary: boundary_kernel's business
     if (sl.status != CCSP_ST_RUNNING) return;
     __builtin_amdgcn_s_setprio(CCSP_ADVANCE_PRIO);       // beside an evaluator launch: the short tree kernels go first
-    load_engine_lines(&lds.T, lane);
-    __syncthreads();
     const bool reuse = (flags & CCSP_ADVANCE_REUSE) != 0;
     uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
     const uint8_t *old = (half ? P.pool : P.pool2) + (uint64_t)g * P.pool_stride;
@@ -1783,6 +1784,7 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
     uint32_t a_exp = 0, a_term = 0, a_sims = 0, a_depth = 0, a_children = 0, a_edges = 0, a_hits = 0, errors = 0;
     Pending pd = load_pending_scalar(P.pend + g);
     bool answered = pd.kind == 1;                         // the evaluator's answer for the leaf this slot asked about last time
+    if (answered) { load_engine_lines(&lds.T, lane); __syncthreads(); }      // the line tables: the move generator's alone (21 cache lines per call)
     // `deadline` (10-ns ticks since the wave began; 0 = none): a wave that has done other work in this call -- the answered leaf's expansion,
     // evaluator-free simulations -- and is later than that gives its selection up (before it, or between two levels of it) and leaves no
     // request: one idle evaluator row instead of a launch that waits for its last wave.  A call that BEGINS with the selection never gives up,
