@@ -356,6 +356,13 @@ def test_c_abi_error_paths(eng):
     assert L.ccsp_expand_backup(e.ctx, p.data_ptr(), v.data_ptr(), None) == ESTATE
     assert L.ccsp_expand_backup_select(e.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(), None) == ESTATE
     assert L.ccsp_expand_backup_select(e.ctx, p.data_ptr(), v.data_ptr(), None, None) == _lib.EINVAL
+    # the free-running entry points: unknown flag bits, tree reuse before its pool exists, a stagger span beyond the slot's 16-bit countdown
+    assert L.ccsp_advance(e.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(), None, 1 << 9, None) == _lib.EINVAL
+    assert L.ccsp_advance(e.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(), None, _lib.ADVANCE_REUSE, None) == ESTATE
+    assert L.ccsp_boundary(e.ctx, p.data_ptr(), v.data_ptr(), None, None, 0, None) == _lib.EINVAL
+    assert L.ccsp_set_stagger_span(e.ctx, 65536) == _lib.EINVAL and L.ccsp_set_stagger_span(e.ctx, -1) == _lib.EINVAL
+    assert L.ccsp_set_stagger_span(e.ctx, 4010) == 0 and L.ccsp_set_stagger_span(None, 1) == _lib.EINVAL
+    assert L.ccsp_debug_read_slots(e.ctx, None) == _lib.EINVAL
     e.close()
 
 
