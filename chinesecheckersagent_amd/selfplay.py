@@ -613,7 +613,11 @@ class SelfPlayRun(object):
         n_games = int(n_games)
         n_slots = max(1, min(n_games, int(max_slots)))
         if n_parts is None:
-            n_parts = 2 if (n_slots >= 2048 and hasattr(_batched(model1), 'model')) else 1
+            # two half-batches from 1024 slots on (measured in steady state at 400 simulations, M node-expansions/s, one part lock-step /
+            # one part free-running / two parts lock-step / two parts free-running: 512 slots 8.1 / 7.1 / 5.7 / 6.4; 1024 slots
+            # 10.5 / 10.4 / 10.9 / 11.6; 2048 slots - / - / 12.7 / 15.8: an evaluator launch of up to 512 positions takes 46 us, one of
+            # up to 1024 76 us -- two halves of 512 overlap their tree work with each other's launch AND get the shorter launch)
+            n_parts = 2 if (n_slots >= 1024 and hasattr(_batched(model1), 'model')) else 1
         n_slots -= n_slots % n_parts
         self.n_games, self.n_slots, self.harvest_every = n_games, n_slots, int(harvest_every)
         kw = dict(sims=sims, seed=seed, first_game=first_game, game_stride=game_stride, max_games=n_games, randomised=randomised,

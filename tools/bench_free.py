@@ -20,6 +20,7 @@ ap.add_argument('--debug', action='store_true')
 ap.add_argument('--boundary-every', type=int, default=0, help='0 = the class default')
 ap.add_argument('--harvest', type=int, default=4)
 ap.add_argument('--unroll', type=int, default=25)
+ap.add_argument('--parts', type=int, default=0, help='half-batches (0 = SelfPlayRun decides)')
 ap.add_argument('--deadlines', default='', help='comma-separated deadlines in microseconds (0 = none)')
 ap.add_argument('--time-caps', default='', help='comma-separated caps in microseconds (0 = none): every budget is run with every cap')
 a = ap.parse_args()
@@ -47,7 +48,7 @@ for kind, budget, *rest in cases:
         L.ccsp_debug_advance_time_cap(int(cap * 100))
     sink = sp.TrainDataSink(); sink.discard = True
     run = sp.SelfPlayRun(m, n_games=a.games * 64, sims=a.sims, seed=20261003, max_slots=a.games, keep_records=False, sink=sink,
-                         free_running=(kind == 'free'), reuse=(False if a.no_reuse else None), harvest_every=a.harvest)
+                         free_running=(kind == 'free'), reuse=(False if a.no_reuse else None), harvest_every=a.harvest, n_parts=(a.parts or None))
     for _ in range(a.spread):
         run.play_ply()
     run.drain()
