@@ -219,24 +219,26 @@ def weights_path():
     return p if os.path.exists(p) else None
 
 
-def net_kernel_alone(model, n_pos, torch, local):
-    """the dominant kernel by itself: net_forward_kernel on the batch one launch of the stepped path carries, 400 back-to-back
-    launches timed with HIP events recorded on the stream the kernel is launched on"""
+def net_kernel_alone(model, req, moves, torch):
+    """the dominant kernel by itself, as the delivered path calls it (ccsp_net_forward_requests on one half-batch's request records --
+    the run's own, as they stood at the end of the timed region): 400 back-to-back launches with NOTHING else on the device, timed
+    with HIP events recorded on the stream the kernel is launched on"""
     from chinesecheckersagent_amd import _lib
     from chinesecheckersagent_amd.engine import _stream_ptr
-    x = torch.rand((n_pos, 343), device='cuda:%d' % local)
     L = _lib.lib()
+    n_pos = req.shape[0]
     packed = model._ensure_packed()
-    p_out = torch.empty((n_pos, 294), dtype=torch.float64, device=x.device)
-    v_out = torch.empty(n_pos, dtype=torch.float32, device=x.device)
+    pk = torch.empty((n_pos, _lib.REQUEST_MOVES), dtype=torch.float64, device=req.device)
+    v_out = torch.empty(n_pos, dtype=torch.float32, device=req.device)
     st = _stream_ptr()
+    torch.cuda.synchronize()
     for _ in range(100):                    # (a short burst right after an idle gap is timed at whatever clock the part is ramping through)
-        L.ccsp_net_forward(packed.data_ptr(), x.data_ptr(), n_pos, None, p_out.data_ptr(), v_out.data_ptr(), st)
+        L.ccsp_net_forward_requests(packed.data_ptr(), req.data_ptr(), moves.data_ptr(), n_pos, pk.data_ptr(), v_out.data_ptr(), st)
     iters = 400
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
-        L.ccsp_net_forward(packed.data_ptr(), x.data_ptr(), n_pos, None, p_out.data_ptr(), v_out.data_ptr(), st)
+        L.ccsp_net_forward_requests(packed.data_ptr(), req.data_ptr(), moves.data_ptr(), n_pos, pk.data_ptr(), v_out.data_ptr(), st)
     e.record()
     torch.cuda.synchronize()
     return a.elapsed_time(e) / iters
@@ -304,15 +306,33 @@ def config3(args, torch, rank, world, local, barrier):
         graphs = [b._graph is not None for b in (run.b.parts if hasattr(run.b, 'parts') else [run.b])]
         if not all(graphs):
             raise RuntimeError('config 3 did not run on captured hipGraphs')
+        if not getattr(run, 'free_running', False) and G >= 1024:
+            raise RuntimeError('config 3 did not run on the free-running path')
+        torch.cuda.synchronize()
+        p0 = parts_[0]
+        if getattr(p0, 'free_running', False):          # one half-batch's requests as they stand: the isolated burst below evaluates these
+            req_alone, moves_alone = p0._req.clone(), p0._moves.clone()
+            asked_now = int((req_alone.view(torch.int32)[:, 8] != 0).sum())
+        else:
+            req_alone = moves_alone = None
+            asked_now = 0
     finally:
         run.close()
         shutil.rmtree(out_dir, ignore_errors=True)
     d = {k: c1[k] - c0[k] for k in c1}
     n_pos = run.n_slots // parts
-    k_ms = net_kernel_alone(model, n_pos, torch, local)
+    if req_alone is None:                               # (a lock-step run of fewer than 1024 slots: requests made up from the log's last positions)
+        from chinesecheckersagent_amd import _lib as _l
+        r_ = np.zeros(n_pos, dtype=_l.REQUEST_DTYPE)
+        r_['state'] = _l.pack_states(np.tile(np.array([42, 35, 43, 28, 36, 44, 6, 13, 5, 20, 12, 4], dtype=np.uint8), (n_pos, 1)))
+        r_['kind'], r_['player'], r_['k'] = 1, 1, 14
+        req_alone = torch.from_numpy(r_.view(np.uint8).reshape(n_pos, 64)).to('cuda:%d' % local)
+        moves_alone = torch.zeros((n_pos, _l.REQUEST_MOVES), dtype=torch.int16, device=req_alone.device)
+        asked_now = n_pos
+    k_ms = net_kernel_alone(model, req_alone, moves_alone, torch)
     return d, dt, dict(n_pos=n_pos, k_ms=k_ms, parts=parts, weights=os.path.basename(w) if w else 'random-init', backend=model.backend,
                        steps=steps, rows_written=int(rows), file_bytes=size, t_play=t_play, t_drain=t_drain, t_write=t_write,
-                       n_slots=run.n_slots, free_running=bool(getattr(run, 'free_running', False)),
+                       n_slots=run.n_slots, free_running=bool(getattr(run, 'free_running', False)), asked_in_isolated_batch=asked_now,
                        net_in_pipeline_ms=(sorted(net_in_pipeline_ms)[len(net_in_pipeline_ms) // 2] if net_in_pipeline_ms else None),
                        net_in_pipeline_samples=len(net_in_pipeline_ms),
                        tree_in_pipeline_ms=(sorted(tree_in_pipeline_ms)[len(tree_in_pipeline_ms) // 2] if tree_in_pipeline_ms else None),
@@ -385,6 +405,10 @@ def config5(args, torch, rank, world, local, dist):
         raise RuntimeError('config 5 made to fail on rank %d (test hook)' % rank)
     if os.environ.get('CCSP_BENCH_TEST_STALL_RANK') == str(rank):    # test hook: this rank never joins the loop's collectives
         time.sleep(3600)
+    # the training step's lazy initialisation (MIOpen kernel choice / build: ~5 s on a fresh box, where the driver runs this; well under a
+    # second with a warm cache) is taken OUT of the iteration and reported on its own, so that train_s is what every later iteration pays
+    t_w = time.time()
+    warm = train.warm_up(device='cuda:%d' % local)
     try:
         t0 = time.time()
         cur, best, it = train.evolve(w, best_model=w, iterations=1, num_self_play=args.config5_games, eval_games=24,
@@ -403,7 +427,8 @@ def config5(args, torch, rank, world, local, dist):
                          'sims/move with %s, augment + save + fit (5 epochs of batch 32%s), arena of 24 games at %d sims with the '
                          '100-move limit' % (args.config5_games, world, args.config5_sims, os.path.basename(w),
                             ', DistributedDataParallel' if dist is not None else '', args.config5_sims),
-                wall_s=wall, selfplay_expansions_per_s=tm['selfplay_expansions'] / tm['selfplay_s'], **tm)
+                wall_s=wall, train_warm_up_s=warm, wall_with_warm_up_s=wall + (t0 - t_w),
+                selfplay_expansions_per_s=tm['selfplay_expansions'] / tm['selfplay_s'], **tm)
 
 
 def main():
@@ -437,6 +462,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    from chinesecheckersagent_amd.selfplay import tune_host_allocator
+    tune_host_allocator()                   # this process is a rank and nothing else: its heap keeps its pages (host side)
     _lib.prefer_blocking_sync(0 if os.environ.get('CCSP_BENCH_ONE_DEVICE') == '1' else local)      # a rank's waits sleep instead of spinning (a host core per rank: DESIGN.md section 8)
     _lib.require_gpu()                      # no CPU fallback: fail loudly
     # functional test hook for 1-GPU boxes: CCSP_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo for
@@ -517,36 +544,47 @@ def main():
         tf = info['n_pos'] * NET_FLOP_PER_EVAL / (k_ms * 1e-3) / 1e12
         done = tot3['games_won'] + tot3['games_discarded']
         launches = steps * (S + 1) * info['parts']                      # evaluator launches of one rank in the timed region
+        hits = tot3.get('cache_hits', 0)
+        rows_carried = steps * (S + 1) * info['n_slots'] * world        # rows of all evaluator launches of the timed region
         out = {
-            'metric': 'mcts_node_expansions_per_s (self-play with the policy/value net, %d games x %d sims/move per GPU; games/s beside it)' % (G, S),
+            'metric': 'mcts_node_expansions_per_s (self-play with the policy/value net, %d games x %d sims/move per GPU; games/s: config.games_per_s)' % (G, S),
             'value': ex / dt3, 'unit': 'node-expansions/s', 'n_gpus': world, 'steps': steps, 'steps_requested': K, 'warmup': W,
             'ms_per_step': dt3 / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'degraded': False,
-            'config': {'workload': 'config 3: %d concurrent games/GPU x %d sims/move, %s through the fused fp32-MFMA evaluator kernel '
-                                   '(float64 PUCT tree), played through selfplay.SelfPlayRun (the API behind selfplay_batch / '
-                                   'generate_self_play): restarting slots in steady state, free-running stepped path (every slot at its own '
-                                   'simulation of its own ply: net -> advance kernel [-> boundary kernel]; positions of the previous tree reused; 25 rounds per hipGraph, %d half-batches on their own streams), '
-                                   'log harvested every %d steps; a step = sims + 1 evaluator launches per half-batch; timed: %d steps + conversion to (board_x, pi_y, v_y) + streaming them into the HDF5 training file; '
-                                   'untimed before: %d plies in which the first cohort of games spreads out + %d warm-up'
-                                   % (G, S, info['weights'], info['parts'], args.harvest_every, steps, args.spread_plies, W),
+            # `config`: SCALAR keys only (the driver's record keeps those and cuts strings at 120 characters): what names the workload first,
+            # then BASELINE.json's first-named metric -- games/s -- and the figures `value` must be read beside
+            'config': {'workload': 'config 3: %d games/GPU x %d sims/move, %s, SelfPlayRun free-running + tree reuse' % (G, S, info['weights']),
                        'games_per_gpu': G, 'sims': S, 'sharding': 'game id mod n_gpus',
-                       # BASELINE.json's first-named metric and what describes the run, kept where the driver's record keeps them
-                       'measured': {'games_per_s': done / dt3, 'games_won_per_s': tot3['games_won'] / dt3,
-                                    'discard_rate': tot3['games_discarded'] / max(done, 1), 'plies_per_game': tot3['plies'] / max(done, 1),
-                                    'timed_region_s_total': dt3, 'node_expansions_per_s': ex / dt3,
-                                    'net_evals_per_s': steps * (S + 1) * info['n_slots'] * world / dt3,      # rows the evaluator launches carried
-                                    'net_evals_asked_per_s': (ex - tot3.get('cache_hits', 0)) / dt3,          # rows that answered a request
-                                    'expansions_from_previous_tree_per_s': tot3.get('cache_hits', 0) / dt3,
-                                    'tree_reuse_hit_rate': tot3.get('cache_hits', 0) / max(ex, 1),
-                                    'terminal_sim_share': tot3['terminal_sims'] / max(tot3['sims'], 1),
-                                    'searched_plies_per_slot_per_step': tot3['mcts_plies'] / max(steps * info['n_slots'] * world, 1),
-                                    # free-running slots do not share a ply: the time in which every slot searches ONE ply on average
-                                    # (what `ms_per_step` was in the lock-step form, where a step is a ply of every slot)
-                                    'ms_per_searched_ply_of_every_slot': dt3 * 1e3 * info['n_slots'] * world / max(tot3['mcts_plies'], 1),
-                                    'free_running': info['free_running'],
-                                    'train_rows_per_s': rows_all / dt3,
-                                    'host_cpu_s_per_rank': [h[0] for h in host], 'host_cpu_cores_busy_per_rank': [h[0] / dt3 for h in host],
-                                    'host_peak_rss_mb_per_rank': [h[1] for h in host], 'usable_cores': usable_cores()}},
+                       'games_per_s': done / dt3, 'games_won_per_s': tot3['games_won'] / dt3,
+                       'node_expansions_per_s': ex / dt3,
+                       'net_evals_per_s': rows_carried / dt3,                              # rows the evaluator launches carried
+                       'net_evals_asked_per_s': (ex - hits) / dt3,                         # rows that answered a request
+                       'tree_reuse_hit_rate': hits / max(ex, 1),                           # expansions answered by the previous ply's tree
+                       'idle_row_share': 1.0 - (ex - hits) / max(rows_carried, 1),         # evaluator rows no slot asked for
+                       'timed_region_s': dt3, 'discard_rate': tot3['games_discarded'] / max(done, 1),
+                       'plies_per_game': tot3['plies'] / max(done, 1), 'train_rows_per_s': rows_all / dt3,
+                       'host_cores_per_rank': max(h[0] for h in host) / dt3, 'host_peak_rss_mb_per_rank': max(h[1] for h in host),
+                       'free_running': info['free_running'], 'half_batches': info['parts'], 'harvest_every_steps': args.harvest_every,
+                       'untimed_steps_before': args.spread_plies + W,
+                       'step': 'sims + 1 = %d evaluator launches per half-batch (a slot plays %.2f searched plies in it)'
+                               % (S + 1, tot3['mcts_plies'] / max(steps * info['n_slots'] * world, 1))},
+            'description': 'config 3: %d concurrent games/GPU x %d sims/move, %s through the fused fp32-MFMA evaluator kernel (float64 PUCT tree), played '
+                           'through selfplay.SelfPlayRun (the API behind selfplay_batch / generate_self_play): restarting slots in steady state, '
+                           'free-running stepped path (every slot at its own simulation of its own ply: [evaluator on the request records -> advance '
+                           'kernel -> boundary kernel every sixth round]; positions of the previous tree reused; 25 rounds per hipGraph, %d half-batches '
+                           'on their own streams), log harvested every %d steps; timed: %d steps + conversion to (board_x, pi_y, v_y) + streaming them '
+                           'into the HDF5 training file; untimed before: %d steps in which the first cohort of games spreads out + %d warm-up'
+                           % (G, S, info['weights'], info['parts'], args.harvest_every, steps, args.spread_plies, W),
+            'measured': {'terminal_sim_share': tot3['terminal_sims'] / max(tot3['sims'], 1),
+                         'expansions_from_previous_tree_per_s': hits / dt3,
+                         'searched_plies_per_slot_per_step': tot3['mcts_plies'] / max(steps * info['n_slots'] * world, 1),
+                         # free-running slots do not share a ply: the time in which every slot searches ONE ply on average
+                         # (what `ms_per_step` was in the lock-step form, where a step is a ply of every slot)
+                         'ms_per_searched_ply_of_every_slot': dt3 * 1e3 * info['n_slots'] * world / max(tot3['mcts_plies'], 1),
+                         'host_cpu_s_per_rank': [h[0] for h in host], 'host_cpu_cores_busy_per_rank': [h[0] / dt3 for h in host],
+                         'host_peak_rss_mb_per_rank': [h[1] for h in host], 'usable_cores': usable_cores()},
+            'tree_reuse_hit_rate': hits / max(ex, 1), 'idle_row_share': 1.0 - (ex - hits) / max(rows_carried, 1),
+            'net_evals_per_s': rows_carried / dt3, 'net_evals_asked_per_s': (ex - hits) / dt3,
             'games_per_s': done / dt3, 'games_won_per_s': tot3['games_won'] / dt3, 'games_finished': done, 'games_won': tot3['games_won'],
             'samples_per_s': tot3['samples'] / dt3, 'plies_per_s': tot3['plies'] / dt3,
             'plies_per_game': tot3['plies'] / max(done, 1), 'discard_rate': tot3['games_discarded'] / max(done, 1),
@@ -588,6 +626,11 @@ def main():
                          'tree_kernels_ms_in_the_same_rounds': info.get('tree_in_pipeline_ms'),      # advance (+ boundary) of the timed round, same events
                          'wall_ms_per_launch': wall_ms,
                          'wall_frac': info['n_pos'] * NET_FLOP_PER_EVAL / (wall_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         # the same by the DRIVER's clock: the whole timed region (harvests, conversion, file close included) / launches
+                         'step_ms_per_launch': dt3 / launches * 1e3,
+                         'frac_by_step': info['n_pos'] * NET_FLOP_PER_EVAL / (dt3 / launches) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         'useful_frac_by_step': (ex - hits) / world * NET_FLOP_PER_EVAL / dt3 / 1e12 / MFMA_F32_PEAK_TFLOPS,   # rows that were asked for only
+                         'asked_rows_in_isolated_batch': info.get('asked_in_isolated_batch'),
                          })(k_in / max(1.0, k_in / wall_ms)))(max_over_ranks_in(info), max(h[2] for h in host) / launches * 1e3),
         }
         try:                                 # HBM bytes of one launch by the counters (static: a --pmc pass cannot run inside this process)
@@ -595,7 +638,9 @@ def main():
             if info['n_pos'] == prof['n']:
                 out['roofline']['traffic'] = (2.0 * prof['fetch_size_kb'] + prof['write_size_kb']) * 1024.0
                 out['roofline']['traffic_source'] = 'static: ' + prof['source']
-                out['roofline']['algorithmic_bytes_per_launch'] = info['n_pos'] * (343 * 4 + 294 * 8 + 4) + 4 * 250880   # planes in, p and v out, the weights once
+                kbar = tot3['sum_children'] / max(ex, 1)
+                # request records in (64 B), their move rows in (2 K), compact priors and v out (8 K + 4), the weights once
+                out['roofline']['algorithmic_bytes_per_launch'] = info['n_pos'] * (64 + 2 * kbar + 8 * kbar + 4) + 4 * 250880
         except (OSError, KeyError, ValueError) as ex:
             out['roofline']['traffic_source'] = 'profiles/counters.json not usable: %r' % (ex,)
         if tot3['errors']:
@@ -792,7 +837,7 @@ def extras(eng, G, S, torch, _lib, engine):
         m = ResidualCNN(device='cuda:%d' % torch.cuda.current_device())
         m.load_weights(weights_path())
         sink = sp.TrainDataSink(); sink.discard = True
-        run = sp.SelfPlayRun(m, n_games=G * 64, sims=S, seed=SEED, max_slots=G, keep_records=False, sink=sink, free_running=False)
+        run = sp.SelfPlayRun(m, n_games=G * 64, sims=S, seed=SEED, max_slots=G, keep_records=False, sink=sink, free_running=False, off_path_ok=True)
         try:
             for _ in range(80):                            # (as many untimed plies as the headline's spread + warm-up: the same steady state)
                 run.play_ply()

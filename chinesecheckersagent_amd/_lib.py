@@ -23,7 +23,8 @@ GREEDY_MAX = 32
  CNT_SUM_DEPTH, CNT_SUM_CHILDREN, CNT_SELECT_EDGES, CNT_SAMPLES, CNT_ERRORS) = range(12)
 CNT_CACHE_HITS = 15
 CNT_COUNT = 16
-ADVANCE_REUSE, ADVANCE_LOG_GUARD, ADVANCE_STAGGER = 1, 2, 4
+ADVANCE_REUSE, ADVANCE_LOG_GUARD, ADVANCE_STAGGER, ADVANCE_DEBUG, ADVANCE_OVERLAPPED = 1, 2, 4, 8, 16
+REQUEST_MOVES = 128
 CNT_NAMES = ['expansions', 'terminal_sims', 'sims', 'plies', 'mcts_plies', 'games_won', 'games_discarded',
              'sum_depth', 'sum_children', 'select_edges', 'samples', 'errors', 'cache_hits']
 CNT_INDEX = {name: (i if i < 12 else 15) for i, name in enumerate(CNT_NAMES)}        # cache_hits = CCSP_CNT_CACHE_HITS (15)
@@ -32,7 +33,10 @@ STATE_DTYPE = np.dtype([('occ', '<u8', (2,)), ('pos', 'u1', (2, 6)), ('last', 'u
 META_DTYPE = np.dtype([('game', '<u8'), ('ply', '<u4'), ('player', 'u1'), ('pad', 'u1', (3,))])
 RESULT_DTYPE = np.dtype([('status', 'u1'), ('reward', 'i1'), ('n_plies', '<u2'), ('n_samples', '<u4'),
                          ('expansions', '<u8')])
-assert STATE_DTYPE.itemsize == 32 and META_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 16
+# one record of the free-running path's request buffer (ccsp_request)
+REQUEST_DTYPE = np.dtype([('state', STATE_DTYPE), ('kind', '<u4'), ('depth', '<u4'), ('link', '<u4'), ('player', '<u4'), ('k', '<u4'),
+                          ('walk', '<u4', (3,))])
+assert STATE_DTYPE.itemsize == 32 and META_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 16 and REQUEST_DTYPE.itemsize == 64
 
 
 class Config(C.Structure):
@@ -79,8 +83,13 @@ _SIGS = {
     'ccsp_expand_backup_select': (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     'ccsp_ply_end': (C.c_int, [_VP, _VP]),
     'ccsp_enable_tree_reuse': (C.c_int, [_VP]),
-    'ccsp_advance': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
-    'ccsp_boundary': (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
+    'ccsp_advance': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
+    'ccsp_boundary': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
+    'ccsp_encode_requests': (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    'ccsp_gather_priors': (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP]),
+    'ccsp_debug_table_eval': (C.c_int, [C.c_int, _VP, _VP, C.c_int, _VP, _VP, _VP]),
+    'ccsp_net_forward_requests': (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP]),
+    'ccsp_set_advance_limits': (C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
     'ccsp_set_stagger_span': (C.c_int, [_VP, C.c_int]),
     'ccsp_debug_advance_budget': (C.c_int, [C.c_int]),
     'ccsp_debug_advance_time_cap': (C.c_int, [C.c_int]),
@@ -120,7 +129,7 @@ def lib():
     return _lib
 
 
-_blocking_sync = [None]
+_blocking_sync = {}
 
 
 def prefer_blocking_sync(device=None):
@@ -130,17 +139,23 @@ def prefer_blocking_sync(device=None):
     throughput; eight ranks on a 16-core quota leave the converter threads no core otherwise.  Best called before the process
     touches the GPU (launch.init_rank and bench.py do); later calls may be refused by the runtime, which is harmless.
     CCSP_NO_BLOCKING_SYNC=1 leaves the runtime's default.  -> the runtime's return code, or None if not attempted."""
-    if _blocking_sync[0] is not None or os.environ.get('CCSP_NO_BLOCKING_SYNC') == '1':
-        return _blocking_sync[0]
+    key = -1 if device is None else int(device)          # the flags are per DEVICE: a run on device N sets them there, once
+    if key in _blocking_sync or os.environ.get('CCSP_NO_BLOCKING_SYNC') == '1':
+        return _blocking_sync.get(key)
     try:
         import torch
         hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))   # the runtime torch has loaded: the process's only one
+        prev = C.c_int(-1)
         if device is not None:
+            if hip.hipGetDevice(C.byref(prev)) != 0:
+                prev.value = -1
             hip.hipSetDevice(int(device))                       # the flags are the current device's
-        _blocking_sync[0] = int(hip.hipSetDeviceFlags(4))
+        _blocking_sync[key] = int(hip.hipSetDeviceFlags(4))
+        if device is not None and prev.value >= 0 and prev.value != int(device):
+            hip.hipSetDevice(prev.value)                        # the caller's current device stays current
     except Exception:
-        _blocking_sync[0] = -1
-    return _blocking_sync[0]
+        _blocking_sync[key] = -1
+    return _blocking_sync[key]
 
 
 def check(rc, what=''):

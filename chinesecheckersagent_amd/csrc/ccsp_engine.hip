@@ -77,15 +77,23 @@ struct SimCtx {
                                   // pre-expansion (selfplay.py:117), 1 in the arena where simulation 0 expands the root
 };
 
-struct Pending {                  // select -> expand_backup hand-off of the stepped path (64 bytes)
+struct Pending {                  // select -> expand_backup hand-off of the stepped path (64 bytes); on the free-running path the
+                                  // record IS the request the evaluator reads (ccsp_request of ccsp.h: same layout)
     ccsp_sr leaf;                 // leaf position
-    uint32_t kind;                // 0 none, 1 expand, 2 terminal
+    uint32_t kind;                // 0 none, 1 expand, 2 terminal; free-running: 1 a leaf / 3, 4 a ply's root asks the evaluator
     uint32_t depth;
     uint32_t link_off;            // byte offset in the pool of the child word to link (or ~0u for the root)
     uint32_t leaf_player;
-    uint32_t pad[4];
+    uint32_t k;                   // free-running: legal moves of `leaf` = entries of the slot's row of the move table and of the answer
+    uint32_t walk_c;              // free-running, kind 0: a selection given up at the deadline goes on in front of this child word ...
+    uint32_t walk_at;             // ... at level (low 16 bits; 0 = no such walk) with Sum(N) (high 16 bits) ...
+    uint32_t walk_edges;          // ... having scanned this many edges so far (the counter of the byte model)
 };
-static_assert(sizeof(Pending) == 64, "Pending must stay 64 bytes");
+static_assert(sizeof(Pending) == 64 && sizeof(Pending) == sizeof(ccsp_request), "Pending must stay 64 bytes");
+static_assert(offsetof(Pending, kind) == offsetof(ccsp_request, kind) && offsetof(Pending, leaf_player) == offsetof(ccsp_request, player) &&
+              offsetof(Pending, k) == offsetof(ccsp_request, k), "ccsp_request is the public face of Pending");
+constexpr int REQ_MV = CCSP_REQUEST_MOVES;     // row stride of the request move table and of the compact answer (entries)
+constexpr uint16_t MV_WINS = 0x8000;           // move-table entry: the move wins (terminal leaf)
 
 constexpr int CCSP_DBG_STRIDE = CCSP_DEBUG_WORDS_PER_SLOT;
 struct Params {
@@ -184,6 +192,16 @@ struct Tally {                    // wave-uniform counters, flushed once per ker
 };
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x; }
+// the lane id through an instruction the compiler cannot hoist: everything wave_movegen derives from the lane (group, direction, axis,
+// strides ...) is then computed WHERE the generator runs.  advance_kernel generates moves behind its simulation loop; with the plain
+// lane id those per-lane constants are hoisted to the top of the kernel, live across the loop and spill to scratch (24-56 dwords per lane:
+// every one four cache lines of traffic beside the evaluator).
+__device__ __forceinline__ int lane_id_here() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 
 // src must be wave-uniform
 __device__ __forceinline__ uint32_t bcast32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
@@ -285,9 +303,9 @@ __device__ __forceinline__ uint64_t path_entry(uint32_t off8, int k, int j) { re
 // rule S1 (selfplay.py:95-98) needs one checker's list, not all six.  NoPick = every checker, the full list.
 struct NoPick { __device__ __forceinline__ int operator()(uint32_t) const { return -1; } };
 
-template <typename Pick>
+template <typename Pick, bool HERE = false>
 __device__ __forceinline__ int wave_movegen_impl(Lds &lds, const ccsp_sr &st, int player, Pick pick) {
-    const int lane = lane_id();
+    const int lane = HERE ? lane_id_here() : lane_id();
     const int grp = lane >> 3, dir = lane & 7;
     const bool act = (grp < 6) & (dir < 6);
     const int g = grp < 6 ? grp : 0, d = dir < 6 ? dir : 0;
@@ -368,8 +386,9 @@ __device__ __forceinline__ int wave_movegen_impl(Lds &lds, const ccsp_sr &st, in
     return total;
 }
 
+template <bool HERE = false>
 __device__ __forceinline__ int wave_movegen(Lds &lds, const ccsp_sr &st, int player) {
-    return wave_movegen_impl(lds, st, player, NoPick());
+    return wave_movegen_impl<NoPick, HERE>(lds, st, player, NoPick());
 }
 
 // entry j of the flattened move list -> (checker id, destination)
@@ -521,10 +540,99 @@ __device__ __forceinline__ int wave_expand(Lds &lds, SimCtx &sl, uint8_t *pool, 
     return K;
 }
 
+// ---- T3 on the free-running path, split around the evaluator: the move list when the request is MADE, the block when the answer COMES ----
+// Request time: Board.get_valid_moves of the position to be evaluated (MCTS.py:95) -> the slot's row of the request move table: action
+// index (utils.encode_checker_index) | MV_WINS where leaf.check_win() holds after the move (MCTS.py:81, decided once, here).  The
+// evaluator's epilogue reads the row and answers with the priors of exactly these moves.  Returns K.
+template <bool HERE = false>      // HERE: see lane_id_here (advance_kernel)
+__device__ __forceinline__ int wave_request_moves(Lds &lds, const ccsp_sr &st, int player, uint16_t *mv_out) {
+    const int K = wave_movegen<HERE>(lds, st, player);
+    const int lane = HERE ? lane_id_here() : lane_id();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int j = lane + 64 * h;
+        if (j < K) {
+            int id, dest;
+            move_of(lds, j, id, dest);
+            const int from = ccsp_sr_pos(st, (player - 1) * 6 + id);
+            const uint64_t flip = (1ULL << from) | (1ULL << dest);
+            const uint64_t o1 = player == 1 ? st.occ0 ^ flip : st.occ0, o2 = player == 2 ? st.occ1 ^ flip : st.occ1;
+            mv_out[j] = (uint16_t)((id * CCSP_NCELL + dest) | (ccsp_check_win(o1, o2) ? MV_WINS : 0));
+        }
+    }
+    return K;
+}
+
+// Answer time: the node block of `st` (MCTS.py:97-109) from the request's move row and the compact answer pk[j] = p[action index of move j]
+// -- no move generation, no line tables, no LDS (NOISE: the root's Dirichlet noise, selfplay.py:121-124, draws through lds.gam).
+template <bool NOISE, bool HERE = false>       // HERE: see lane_id_here
+__device__ __forceinline__ int wave_expand_answer(Lds *lds, SimCtx &sl, uint8_t *pool, const ccsp_sr &st, int player, int K,
+                                                  const uint16_t *mv, const double *pk, float v, uint32_t &off_out) {
+    const int lane = HERE ? lane_id_here() : lane_id();
+    const uint32_t off = sl.pool_used;
+    off_out = off;
+    if (K == 0) return 0;                               // stays a leaf (MCTS.py:95-109 adds no edge)
+    uint8_t *b = pool + off;
+    sl.pool_used = off + block_bytes(K);
+    if (lane == 0) {
+        ccsp_store_sr(reinterpret_cast<ccsp_state *>(b), st);
+        reinterpret_cast<uint32_t *>(b + 32)[0] = (uint32_t)K;
+        reinterpret_cast<uint32_t *>(b + 32)[1] = (uint32_t)player;
+        reinterpret_cast<uint32_t *>(b + 32)[2] = 0u;                  // no shadow: the position was not in the previous ply's tree
+        reinterpret_cast<float *>(b + 32)[3] = v;
+    }
+    double pr[2] = {0.0, 0.0};
+    uint32_t m[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int j = lane + 64 * h;
+        if (j < K) { pr[h] = pk[j]; m[h] = mv[j]; }
+    }
+    if (NOISE) {                                        // selfplay.py:121-124 (the arithmetic of wave_expand)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int j = lane + 64 * h;
+            if (j < K) lds->gam[j] = ccsp_gamma_small(sl.hgame, sl.ply, (uint32_t)j, CCSP_DIRICHLET_ALPHA);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            double s = 0.0;
+            for (int j = 0; j < K; j++) s = s + lds->gam[j];
+            lds->gam[CCSP_MAX_MOVES] = s;
+        }
+        __syncthreads();
+        const double s = lds->gam[CCSP_MAX_MOVES];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int j = lane + 64 * h;
+            if (j < K) {
+                const double noise = (s == 0.0) ? 1.0 / (double)K : lds->gam[j] / s;
+                double p = pr[h];
+                p = p * (1. - CCSP_DIR_NOISE_FACTOR);
+                p = p + CCSP_DIR_NOISE_FACTOR * noise;
+                pr[h] = p;
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int j = lane + 64 * h;
+        if (j < K) {
+            blk_P(b, K)[j] = pr[h];
+            blk_W(b, K)[j] = 0.0;
+            blk_N(b, K)[j] = 0u;
+            blk_child(b, K)[j] = (m[h] & MV_WINS) ? CHILD_TERMINAL : CHILD_LEAF;
+            blk_mv(b, K)[j] = (uint16_t)(m[h] & 0x7FFFu);
+        }
+    }
+    return K;
+}
+
 // ---- T2: MCTS.moveToLeaf --------------------------------------------------------------------------
 struct Leaf {
-    int kind;                     // 1 expand, 2 terminal
+    int kind;                     // 1 expand, 2 terminal; 0 = the walk was given up after `depth` levels (ccsp_advance's deadline)
     int depth;
+    uint32_t next_c, next_nsum;   // kind 0: the child word of the node the walk stopped in front of and its Sum(N) -- where it goes on
     uint32_t parent_shadow;       // SHADOW only: header word "shadow" of the block the last edge leaves from
     int parent_k, sel;            // that block's edge count and the edge taken
     uint32_t link_off;            // pool offset of the child word of the last edge
@@ -545,7 +653,9 @@ __device__ __forceinline__ Pick pick_edge(const double *__restrict__ sqrt_tab, c
     double qu[H], wv[H]; uint32_t n[H], ch[H], mv[H];
 #pragma unroll
     for (int h = 0; h < H; h++) {
-        const int j = lane + 64 * h;
+        // (the second half -- nodes of more than 64 edges, rare -- takes the lane id through lane_id_here(): its offsets are then computed
+        // when needed instead of living in four vector registers for the whole kernel)
+        const int j = h ? lane_id_here() + 64 : lane;
         qu[h] = -INFINITY; wv[h] = 0.0; n[h] = 0; ch[h] = 0; mv[h] = 0;
         if (j < K) {
             // the five arrays through scalar base + 32-bit lane offset: the offsets are pinned inside the loop (an empty asm), or their
@@ -609,16 +719,29 @@ __device__ __forceinline__ Pick pick_edge(const double *__restrict__ sqrt_tab, c
 #endif
 // `give_up_at` (ccsp_advance): a value of the 100 MHz clock (its low 32 bits) past which the walk is abandoned at the next level (Leaf.kind 0; nothing has been
 // changed: the caller selects again in its next call); 0 = never
+// `from` (ccsp_advance): a walk given up earlier goes on where it stopped -- at level from->level, in front of the node of child word
+// from->c with Sum(N) from->nsum; the path so far is in path[0 .. level) (nothing in the tree has changed in between: the slot is its
+// only writer, and the draws of a level are keyed by (ply, simulation, level)).
+struct WalkFrom { uint32_t c, nsum; int level; };
 template <bool RCP, bool REGPATH = RCP, bool SHADOW = false>   // RCP: divisions through a table of reciprocals; REGPATH: the caller keeps the path's first 64 levels in registers; SHADOW: tree reuse (ccsp_advance)
 __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab, const double *rcp, const SimCtx &sl, uint8_t *pool, uint64_t *path, uint32_t sim,
-                                            uint64_t &mypath, double &myW, uint32_t &myN, uint32_t &select_edges, uint32_t give_up_at = 0) {
+                                            uint64_t &mypath, double &myW, uint32_t &myN, uint32_t &select_edges, uint32_t give_up_at = 0,
+                                            const WalkFrom from = WalkFrom{0u, 0u, 0}) {
     const int lane = lane_id();
     uint32_t off = 0;
     int K = (int)sl.root_k;
     uint32_t nsum = sim - sl.nsum_bias;                 // Sum(N) over the root's edges
     int level = 0;
     int player = sl.player;
+    if (from.level != 0) {                              // (rare: the lanes of the levels already walked fetch what the walk left in them)
+        off = (from.c >> 7) << 3; K = (int)(from.c & 127); nsum = from.nsum; level = from.level;
+        if (level & 1) player = 3 - player;
+        // (the lanes of the levels already walked hold nothing: the caller fetches their path entries and statistics after the walk,
+        // walk_rejoin below; the path stores here leave their entries in memory alone)
+    }
+    const int lane0 = from.level < 64 ? from.level : 64;
     Leaf out;
+    out.next_c = 0; out.next_nsum = 0;
     for (;;) {
         uint8_t *b = pool + off;
         int sel;
@@ -650,7 +773,12 @@ __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab,
         if (level >= 64 && lane == 0) path[level] = entry;                 // (the first 64 levels: in `mypath`; written out below where the caller does not keep them)
         level++;
         if (c_sel != CHILD_LEAF && c_sel != CHILD_TERMINAL) {       // descend (MCTS.py:74)
-            if (CCSP_ADVANCE_DEADLINE_CODE && SHADOW && give_up_at != 0 && (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - give_up_at) > 0) { out.kind = 0; out.depth = level; return out; }
+            if (CCSP_ADVANCE_DEADLINE_CODE && SHADOW && give_up_at != 0 && (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - give_up_at) > 0) {
+                // given up between two levels: the path so far goes to memory, the caller records where the walk goes on
+                if (lane >= lane0 && lane < (level < 64 ? level : 64)) path[lane] = mypath;
+                out.kind = 0; out.depth = level; out.next_c = c_sel; out.next_nsum = n_sel - 1;
+                return out;
+            }
             off = (c_sel >> 7) << 3;
             K = (int)(c_sel & 127);
             nsum = n_sel - 1;
@@ -660,7 +788,7 @@ __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab,
         out.depth = level;
         // the path for the kernel (or call) that backs this leaf up: ONE store of the lanes' entries instead of one per level from lane 0 -- a
         // store between two levels' loads makes the next level's wait (the counter runs in order) wait for the store's acknowledgement too
-        if (!REGPATH && lane < (level < 64 ? level : 64)) path[lane] = mypath;
+        if (!REGPATH && lane >= lane0 && lane < (level < 64 ? level : 64)) path[lane] = mypath;
         out.parent_shadow = hdr_shadow; out.parent_k = K; out.sel = sel;
         out.link_off = off + BLOCK_HDR + 20 * K + 4 * sel;
         out.player = 3 - player;
@@ -673,11 +801,24 @@ __device__ __forceinline__ Leaf wave_select(const double *__restrict__ sqrt_tab,
     }
 }
 
+// a resumed walk (WalkFrom) has reached its leaf: the lanes of the levels walked in the EARLIER call fetch their path entries and the
+// statistics of their edges, as if the walk had been made in one go
+__device__ __forceinline__ void walk_rejoin(uint8_t *pool, const uint64_t *path, int from_level, uint64_t &mypath, double &myW, uint32_t &myN) {
+    const int lane = lane_id_here();
+    if (lane < (from_level < 64 ? from_level : 64)) {
+        mypath = path[lane];
+        uint8_t *pb = pool + ((mypath >> 16) << 3);
+        const int pk_ = (int)((mypath >> 8) & 0xFF), pj = (int)(mypath & 0xFF);
+        myN = blk_N(pb, pk_)[pj]; myW = blk_W(pb, pk_)[pj];
+    }
+}
+
 // ---- T3 (backup half): MCTS.py:83-90 (terminal) and 112-118 ---------------------------------------
 // `have_stats`: the W and N of the first 64 path edges were kept in registers by wave_select (fused path)
+template <bool HERE = false>       // HERE: see lane_id_here
 __device__ __forceinline__ void wave_backup(uint8_t *pool, const uint64_t *path, uint64_t mypath, double myW, uint32_t myN,
                                             bool have_stats, int depth, bool terminal, float v) {
-    const int lane = lane_id();
+    const int lane = HERE ? lane_id_here() : lane_id();
     for (int i0 = 0; i0 < depth; i0 += 64) {
         const int i = i0 + lane;
         if (i < depth) {
@@ -1290,11 +1431,12 @@ __device__ __forceinline__ void store_slot_search(SlotMem *p, const Slot &s) {  
     }
 }
 __device__ __forceinline__ Pending load_pending_scalar(const Pending *p) {
-    u32x8 a; u32x4 b;
-    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+    u32x16 a;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(p) : "memory");
     Pending pd;
     pd.leaf.occ0 = pair64(a[0], a[1]); pd.leaf.occ1 = pair64(a[2], a[3]); pd.leaf.a = pair64(a[4], a[5]); pd.leaf.b = pair64(a[6], a[7]);
-    pd.kind = b[0]; pd.depth = b[1]; pd.link_off = b[2]; pd.leaf_player = b[3];
+    pd.kind = a[8]; pd.depth = a[9]; pd.link_off = a[10]; pd.leaf_player = a[11];
+    pd.k = a[12]; pd.walk_c = a[13]; pd.walk_at = a[14]; pd.walk_edges = a[15];
     return pd;
 }
 __device__ __forceinline__ Slot empty_slot() {
@@ -1603,7 +1745,7 @@ __global__ __launch_bounds__(64) void expand_backup_select_kernel(Params P, cons
 // the current tree -- what wave_expand writes for that position with the evaluator's answer, without generating the moves again:
 // same position = same move list in the same order, same priors, same won-leaf marks; statistics start from zero (MCTS.py:97-109).
 __device__ __forceinline__ int wave_copy_block(SimCtx &sl, uint8_t *pool, const uint8_t *ob, uint32_t shadow, uint32_t &off_out) {
-    const int lane = lane_id();
+    const int lane = lane_id_here();                    // (see lane_id_here: nothing of this block lives outside it)
     const uint4 h0 = *reinterpret_cast<const uint4 *>(ob), h1 = *reinterpret_cast<const uint4 *>(ob + 16), h2 = *reinterpret_cast<const uint4 *>(ob + 32);
     const int K = (int)uni32(h2.x);
     const uint32_t off = sl.pool_used;
@@ -1656,23 +1798,31 @@ __device__ __forceinline__ int wave_copy_block(SimCtx &sl, uint8_t *pool, const 
 // spent a slot selects once more and leaves its request if that leaf needs the evaluator -- otherwise it completes that one
 // simulation too (the walk is done) and returns without a request (its row of the next evaluator launch is idle).  With `time_cap`
 // and `deadline` (below) it bounds the launch's length.
-__device__ __forceinline__ void write_w15(const Params &P, int g, uint32_t phase, uint32_t half, uint32_t root_shadow) {
-    if (lane_id() == 0) P.slots[g].w[15] = (uint64_t)phase | ((uint64_t)half << 8) | (1ULL << 9) | ((uint64_t)root_shadow << 32);   // (bit 9: the start delay is spent)
+// (bit 9: the start delay is spent; bits 10-11 `fin`: bit 11 = a free-running ply of this slot has been finished, bit 10 = the pool that
+// holds ITS tree -- what ccsp_read_root / ccsp_debug_tree_digest read: with tree reuse it stays whole while the next ply is searched)
+// bit 12: a root request of this slot is with the evaluator (the request buffer is the caller's: see boundary_kernel)
+__device__ __forceinline__ void write_w15(const Params &P, int g, uint32_t phase, uint32_t half, uint32_t root_shadow, uint32_t fin, bool asked = false) {
+    if (lane_id() == 0) P.slots[g].w[15] = (uint64_t)phase | ((uint64_t)half << 8) | (1ULL << 9) | ((uint64_t)fin << 10) | ((uint64_t)(asked ? 1 : 0) << 12) |
+                                           ((uint64_t)root_shadow << 32);
 }
 
 #ifndef CCSP_ADVANCE_PRIO
 #define CCSP_ADVANCE_PRIO 2
 #endif
-__global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, int stagger) {
+__global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double *pk, const float *v, Pending *req, uint16_t *moves, uint8_t *model_sel, int flags, int stagger) {
     __shared__ Lds lds;
     const int g = blockIdx.x, lane = lane_id();
     const uint64_t w15 = uni64(P.slots[g].w[15]);
-    uint32_t phase = (uint32_t)(w15 & 0xFF), half = (uint32_t)((w15 >> 8) & 1), root_shadow = (uint32_t)(w15 >> 32);
-    const uint32_t kind = uni32(P.pend[g].kind);
+    uint32_t phase = (uint32_t)(w15 & 0xFF), half = (uint32_t)((w15 >> 8) & 1), root_shadow = (uint32_t)(w15 >> 32), fin = (uint32_t)((w15 >> 10) & 3);
     if (phase == 1) return;                               // in a search: advance_kernel's business
-    // A root request is two calls old when its answer is taken: this kernel may run BESIDE the evaluator launch that follows the
-    // call which wrote the planes (the caller's side stream), so that launch's answer is not to be trusted -- the next one's is.
-    if (kind == 4) { if (lane == 0) P.pend[g].kind = 3; return; }
+    // a root request of THIS context is outstanding (bit 12 of word 15): only then does the record's kind mean anything -- the request
+    // buffer is the caller's, and what it holds after a ccsp_reset / ccsp_set_positions is not to be trusted
+    const bool asked = ((w15 >> 12) & 1) != 0;
+    const uint32_t kind = asked ? uni32(req[g].kind) : 0u;
+    // CCSP_ADVANCE_OVERLAPPED: this kernel runs BESIDE the evaluator launch that follows the call which wrote the request (the caller's
+    // side stream), so that launch's answer is not to be trusted -- the next one's is: such a root request (kind 4) is two calls old
+    // when its answer is taken.  In stream order (the default) the very next evaluator launch answers it (kind 3 at once).
+    if (kind == 4) { if (lane == 0) req[g].kind = 3; return; }
     // STAGGERED START: every slot's first game would begin in the same call and -- plies taking similar numbers of calls -- the slots
     // would end their plies in waves for dozens of plies: calls in which most slots are at the cheap middle of a search alternate with
     // calls in which most are at its expensive start (the reused top of the tree: simulation after simulation without the
@@ -1693,13 +1843,19 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     __syncthreads();
     const bool reuse = (flags & CCSP_ADVANCE_REUSE) != 0;
     uint32_t *acc = P.stepacc + (size_t)g * 8;
+    uint16_t *mv_row = moves + (size_t)g * REQ_MV;
     Tally tl; tally_zero(tl);
-    bool expand_root = false;
-    EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = 0.0f; ev.p_edges = nullptr; ev.shadow = 0;
-    uint32_t hit = 0, request = 0;
-    if (kind == 3) {                                      // the evaluator's answer for this ply's root (root_expand_kernel)
-        ev.v_ext = v[g];
-        expand_root = true;
+    uint32_t request = 0, req_k = 0;
+    if (kind == 3) {                                      // the evaluator's answer for this ply's root (root_expand_kernel): selfplay.py:117-124
+        const int K = (int)uni32(req[g].k);
+        uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
+        SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = 0; cx.player = sl.player; cx.pool_used = 0; cx.nsum_bias = 0;
+        uint32_t off;
+        wave_expand_answer<true>(&lds, cx, pool, sl.st, (int)sl.player, K, mv_row, pk + (size_t)g * REQ_MV, v[g], off);
+        sl.root_k = (uint32_t)K; sl.pool_used = cx.pool_used; sl.sim = 0; sl.expansions += 1;
+        if (K == 0) { sl.status = CCSP_ST_ERROR; tl.errors += 1; }             // assert, selfplay.py:118
+        if (lane == 0) { acc[0] += 1u; acc[4] += (uint32_t)K; }
+        phase = 1;
     } else {
         if (phase == 2) {                                 // the ply's search is done: pi, move, rules, log row (ply_end_kernel)
             // the sample log is shared by the slots and emptied by the host every few plies: a slot that could find it full waits
@@ -1721,6 +1877,7 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
             if (lane < 8) acc[lane] = 0u;
             __syncthreads();
             root_shadow = (reuse && sl.status == CCSP_ST_RUNNING && sl.game == game0 && cw != CHILD_LEAF && cw != CHILD_TERMINAL) ? (cw >> 7) : 0u;
+            fin = 2u | half;                              // the finished ply's tree: in this pool
             if (reuse) half ^= 1u;                        // the tree just searched stays where it is; the next ply grows in the other pool
             phase = 0;
         }
@@ -1729,30 +1886,33 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
         if (sl.status == CCSP_ST_RUNNING && sl.opening_left == 0) {
             if (reuse && root_shadow != 0) {              // the root was a node of the previous ply's tree: its priors and value are there
                 const uint8_t *ob = (half ? P.pool : P.pool2) + (uint64_t)g * P.pool_stride + ((uint64_t)root_shadow << 3);
-                ev.kind = CCSP_EVAL_CACHED; ev.p_edges = reinterpret_cast<const double *>(ob + BLOCK_HDR);
+                EvalCtx ev; ev.kind = CCSP_EVAL_CACHED; ev.p_row = nullptr; ev.p_edges = reinterpret_cast<const double *>(ob + BLOCK_HDR);
                 ev.v_ext = reinterpret_cast<const float *>(ob + 32)[3]; ev.shadow = root_shadow;
-                expand_root = true; hit = 1;
-            } else {
-                wave_encode(lds, sl.st, (int)sl.player, planes + (uint64_t)g * CCSP_PLANES);
-                request = 4;
+                uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
+                SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = 0; cx.player = sl.player; cx.pool_used = 0; cx.nsum_bias = 0;
+                uint32_t off;
+                const int K = wave_expand(lds, cx, pool, sl.st, (int)sl.player, ev, 0, true, off);       // selfplay.py:117-124
+                sl.root_k = (uint32_t)K; sl.pool_used = cx.pool_used; sl.sim = 0; sl.expansions += 1;
+                if (K == 0) { sl.status = CCSP_ST_ERROR; tl.errors += 1; }
+                if (lane == 0) { acc[0] += 1u; acc[4] += (uint32_t)K; acc[6] += 1u; }
+                phase = 1;
+            } else {                                      // ask the evaluator: the root's move list now, its block when the answer comes
+                req_k = (uint32_t)wave_request_moves(lds, sl.st, (int)sl.player, mv_row);
+                request = (flags & CCSP_ADVANCE_OVERLAPPED) ? 4u : 3u;
             }
         }
     }
-    if (expand_root) {                                    // selfplay.py:117-124: expansion + Dirichlet noise
-        uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
-        SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = 0; cx.player = sl.player; cx.pool_used = 0; cx.nsum_bias = 0;
-        uint32_t off;
-        const int K = wave_expand(lds, cx, pool, sl.st, (int)sl.player, ev, 0, true, off);
-        sl.root_k = (uint32_t)K; sl.pool_used = cx.pool_used; sl.sim = 0; sl.expansions += 1;
-        if (K == 0) { sl.status = CCSP_ST_ERROR; tl.errors += 1; }             // assert, selfplay.py:118
-        if (lane == 0) { acc[0] += 1u; acc[4] += (uint32_t)K; acc[6] += hit; }
-        phase = 1;
-    }
     if (lane == 0) {
-        P.pend[g].kind = request;
+        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(req + g);
+        if (request) {
+            q[0] = make_ulonglong2(sl.st.occ0, sl.st.occ1);
+            q[1] = make_ulonglong2(sl.st.a, sl.st.b);
+        }
+        q[2] = make_ulonglong2((uint64_t)request, (uint64_t)~0u | ((uint64_t)sl.player << 32));
+        q[3] = make_ulonglong2((uint64_t)req_k, 0ULL);   // (no walk to resume)
         if (request && model_sel) model_sel[g] = (uint8_t)(sl.player == 2 ? 1 : 0);    // whose model answers (selfplay.py:30,36,59)
     }
-    write_w15(P, g, phase, half, root_shadow);
+    write_w15(P, g, phase, half, root_shadow, fin, request != 0);
     store_slot(P.slots + g, sl);
     tally_flush(P, tl);
 }
@@ -1760,20 +1920,27 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
 #ifndef CCSP_ADVANCE_WAVES
 #define CCSP_ADVANCE_WAVES 6
 #endif
+struct AdvArgs {                  // advance_kernel's arguments (see the kernel's first lines)
+    Params P;
+    const double *pk; const float *v; Pending *req; uint16_t *moves; uint8_t *model_sel;
+    int flags, budget, time_cap, deadline;
+};
 template <bool DBG>       // DBG: the per-phase cycle stamps (CCSP_ADVANCE_DEBUG) -- a build of their own: their ten 64-bit sums cost the plain kernel twenty scalar registers
-__global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params P_in_kernarg, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, int budget, int time_cap, int deadline) {
-    // The parameter block is read where it is used, through the kernel-argument segment (scalar loads), instead of by name: named, all of it
-    // is loaded in the first block and what the selection loop does not need is parked in vector-register lanes for the whole call
+__global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(AdvArgs args_in_kernarg) {
+    // The arguments are read where they are used, through the kernel-argument segment (scalar loads), instead of by name: named, all of them
+    // are loaded in the first block and what the selection loop does not need is parked in vector-register lanes for the whole call
     // (v_writelane / v_readlane: vector instructions, which is what a tree wave must not spend beside an evaluator launch).
-    const Params &P = *(const Params *)__builtin_amdgcn_kernarg_segment_ptr();
-    static_assert(offsetof(Params, slots) == 0, "Params is the kernel's first argument");
+    const AdvArgs &A = *(const AdvArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const Params &P = A.P;
+    static_assert(offsetof(AdvArgs, P) == 0 && offsetof(Params, slots) == 0, "the parameter block comes first");
+    const int flags = A.flags, budget = A.budget, time_cap = A.time_cap, deadline = A.deadline;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_LIGHT];      // the struct without its last member (pi / gam / rcp: never touched here)
     Lds &lds = *reinterpret_cast<Lds *>(lds_raw);
     const int g = blockIdx.x, lane = lane_id();
     uint64_t w15;
     Slot sl = load_slot_scalar(P.slots + g, w15);
     uint32_t phase = (uint32_t)(w15 & 0xFF);
-    const uint32_t half = (uint32_t)((w15 >> 8) & 1), root_shadow = (uint32_t)(w15 >> 32);
+    const uint32_t half = (uint32_t)((w15 >> 8) & 1), root_shadow = (uint32_t)(w15 >> 32), fin = (uint32_t)((w15 >> 10) & 3);
     if (phase != 1) return;                               // at a ply boundary: boundary_kernel's business
     if (sl.status != CCSP_ST_RUNNING) return;
     __builtin_amdgcn_s_setprio(CCSP_ADVANCE_PRIO);       // beside an evaluator launch: the short tree kernels go first
@@ -1781,19 +1948,22 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
     uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
     const uint8_t *old = (half ? P.pool : P.pool2) + (uint64_t)g * P.pool_stride;
     uint64_t *path = P.path + (uint64_t)g * P.path_stride;
-    uint32_t a_exp = 0, a_term = 0, a_sims = 0, a_depth = 0, a_children = 0, a_edges = 0, a_hits = 0, errors = 0;
-    Pending pd = load_pending_scalar(P.pend + g);
-    bool answered = pd.kind == 1;                         // the evaluator's answer for the leaf this slot asked about last time
-    if (answered) { load_engine_lines(&lds.T, lane); __syncthreads(); }      // the line tables: the move generator's alone (21 cache lines per call)
+        uint32_t a_exp = 0, a_term = 0, a_sims = 0, a_depth = 0, a_children = 0, a_edges = 0, a_hits = 0, errors = 0;
+    Pending pd = load_pending_scalar(A.req + g);            // (phase 1: the record was written by this context's kernels)
+    const bool answered = pd.kind == 1;                   // the evaluator's answer for the leaf this slot asked about last time
+    // a selection this slot gave up at the deadline of its last call: it goes on where it stopped (WalkFrom)
+    WalkFrom walk; walk.c = pd.walk_c; walk.nsum = pd.walk_at >> 16; walk.level = answered ? 0 : (int)(pd.walk_at & 0xFFFFu);
+    uint32_t walk_edges = walk.level != 0 ? pd.walk_edges : 0u;
     // `deadline` (10-ns ticks since the wave began; 0 = none): a wave that has done other work in this call -- the answered leaf's expansion,
     // evaluator-free simulations -- and is later than that gives its selection up (before it, or between two levels of it) and leaves no
     // request: one idle evaluator row instead of a launch that waits for its last wave.  A call that BEGINS with the selection never gives up,
     // so the slot moves on in its next call whatever the deadline.
     const bool began_with_work = answered;
-    uint32_t request = 0;
+    uint32_t request = 0, req_k = 0;
+    uint32_t left_c = 0, left_at = 0, left_edges = 0;     // a walk given up in THIS call
     int spent = 0;
     // diagnostic (CCSP_ADVANCE_DEBUG): cycles of this wave per phase -- [0] set-up, [1] expansion, [2] backup, [3] selection + shadow,
-    // [4] encode + hand-off, [5] whole call, [6] calls, [7] expansions, [8] selections -- summed over the waves into P.dbg
+    // [4] move list + hand-off, [5] whole call, [6] calls, [7] expansions, [8] selections -- summed over the waves into P.dbg
     constexpr bool dbg = DBG;
     unsigned long long t_exp = 0, t_bak = 0, t_sel = 0, t_enc = 0, n_exp = 0, n_sel = 0, tq = 0;
     const unsigned long long t_begin = dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -1805,38 +1975,35 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
 #define ADV_LAP(acc) do { if (dbg) { if (CCSP_ADVANCE_LAP_WAITS) __builtin_amdgcn_s_waitcnt(0); tq = __builtin_amdgcn_s_memtime(); acc += tq - t_mark; t_mark = tq; } } while (0)
     unsigned long long t_setup = 0;
     ADV_LAP(t_setup);
-    // (1) the leaf this slot asked about last time: expansion with the evaluator's (p, v) + backup (expand_backup_core) -- once per call and
-    // AHEAD of the loop, like the plane encoder behind it: the move generator's and the encoder's per-lane constants are then not alive across
-    // the selection loop (inside it they were hoisted to the top of the kernel and spilled to scratch: on gfx950 every reload's wait also
-    // waits for all stores issued before it, and every scratch dword is four cache lines of traffic beside the evaluator)
+    // (1) the leaf this slot asked about last time: its block from the request's move row and the compact answer (no move generation, no
+    // LDS: the list was made when the request was) + backup -- once per call and AHEAD of the loop
     if (answered) {
         const ccsp_sr leaf = pd.leaf; const int leaf_player = (int)pd.leaf_player, depth = (int)pd.depth; const uint32_t link_off = pd.link_off;
-        EvalCtx ev; ev.kind = CCSP_EVAL_EXTERNAL; ev.p_row = p + (uint64_t)g * CCSP_NUM_ACTIONS; ev.v_ext = v[g]; ev.p_edges = nullptr; ev.shadow = 0;
-        const uint64_t mypath = (lane < depth) ? path[lane] : 0;
+        const float val = A.v[g];
+        const int lane1 = lane_id_here();                 // (this phase's lane-derived values die with it)
+        const uint64_t mypath = (lane1 < depth) ? path[lane1] : 0;
         SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = sl.root_k; cx.player = sl.player; cx.pool_used = sl.pool_used; cx.nsum_bias = 0;
         uint32_t noff;
-        const int k = wave_expand(lds, cx, pool, leaf, leaf_player, ev, 0, false, noff);
+        const int k = wave_expand_answer<false, true>(nullptr, cx, pool, leaf, leaf_player, (int)pd.k, A.moves + (size_t)g * REQ_MV, A.pk + (size_t)g * REQ_MV, val, noff);
         sl.pool_used = cx.pool_used;
-        if (k > 0 && lane == 0) *reinterpret_cast<uint32_t *>(pool + link_off) = ((noff >> 3) << 7) | (uint32_t)k;
+        if (k > 0 && lane1 == 0) *reinterpret_cast<uint32_t *>(pool + link_off) = ((noff >> 3) << 7) | (uint32_t)k;
         a_exp += 1; a_children += (uint32_t)k; sl.expansions += 1;
         __syncthreads();
         n_exp += 1;
         ADV_LAP(t_exp);
-        wave_backup(pool, path, mypath, 0.0, 0u, false, depth, false, ev.v_ext);
+        wave_backup<true>(pool, path, mypath, 0.0, 0u, false, depth, false, val);
         sl.sim += 1;
         __syncthreads();                                  // this simulation's stores before the next one's loads
         ADV_LAP(t_bak);
     }
     // (2) selection -- and on through won leaves and reused positions -- until a leaf needs the evaluator or the call's budget is spent
-    ccsp_sr req_leaf; int req_player = 0;
-    req_leaf.occ0 = req_leaf.occ1 = req_leaf.a = req_leaf.b = 0;
     for (;;) {
         ccsp_sr leaf; int leaf_player, depth; uint32_t link_off;
         uint64_t mypath = 0; double myW = 0.0; uint32_t myN = 0;
         bool terminal = false, have_stats = false, stop_after = false;
         EvalCtx ev; ev.kind = CCSP_EVAL_CACHED; ev.p_row = nullptr; ev.v_ext = 0.0f; ev.p_edges = nullptr; ev.shadow = 0;
         if (sl.sim >= (uint32_t)P.sims) { phase = 2; break; }      // the search is done: boundary_kernel ends the ply in the next call
-        // budget spent: one more selection -- its leaf's planes go out if it asks the evaluator; a won or reused leaf is still backed up
+        // budget spent: one more selection -- its leaf's request goes out if it asks the evaluator; a won or reused leaf is still backed up
         // (the walk to it is the expensive part and is done), and the call ends there.  The budget is a number of simulations AND, past
         // the first one, a time (`time_cap`, 10-ns ticks since the wave began): a launch lasts as long as its slowest wave, and the
         // waves that go on through reused positions are the slowest -- a wave that has already been running for longer than the
@@ -1854,12 +2021,18 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
         // the two IEEE divisions per edge and level through the table of reciprocals (read from global memory here: 3.4 KB, cached --
         // the LDS copy the fused kernel keeps would cost this kernel four of its workgroups per CU): 28 vector instructions fewer
         // per edge; beside the evaluator every vector instruction of a tree wave waits for a gap between two MFMAs
-        const Leaf lf = reuse ? wave_select<CCSP_ADVANCE_RCP != 0, false, true>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges, give_up_at)
-                              : wave_select<CCSP_ADVANCE_RCP != 0, false, false>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges);
-        if (lf.kind == 0) break;                      // given up between two levels: nothing was changed
+        const Leaf lf = reuse ? wave_select<CCSP_ADVANCE_RCP != 0, false, true>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges, give_up_at, walk)
+                              : wave_select<CCSP_ADVANCE_RCP != 0, false, false>(P.sqrt_tab, P.rcp_tab, cx, pool, path, sl.sim, mypath, myW, myN, edges, 0, walk);
+        edges += walk_edges;                          // (a resumed walk: the edges its first part scanned)
+        if (walk.level != 0 && lf.kind != 0) walk_rejoin(pool, path, walk.level, mypath, myW, myN);
+        walk.level = 0; walk_edges = 0;
+        have_stats = true;
+        if (lf.kind == 0) {                           // given up between two levels: nothing was changed; the next call goes on from there
+            left_c = lf.next_c; left_at = (uint32_t)lf.depth | (lf.next_nsum << 16); left_edges = edges;
+            break;
+        }
         a_sims += 1; a_depth += (uint32_t)lf.depth; a_edges += edges;
         leaf = lf.st; leaf_player = lf.player; depth = lf.depth; link_off = lf.link_off;
-        have_stats = true;
         n_sel += 1;
         if (lf.kind == 2) {                           // a won leaf: backed up at once (MCTS.py:81-90)
             stop_after = last;                        // budget spent: this simulation is still completed (its selection is done), nothing after it
@@ -1871,21 +2044,28 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
                 const uint32_t cw = uni32(*reinterpret_cast<const uint32_t *>(opb + BLOCK_HDR + 20 * lf.parent_k + 4 * lf.sel));
                 if (cw != CHILD_LEAF && cw != CHILD_TERMINAL) shadow = cw >> 7;
             }
-            if (shadow == 0) {                        // the evaluator is needed: the hand-off record for the next call; the leaf's planes go out behind the loop
-                if (lane == 0) {
-                    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(P.pend + g);
+            if (shadow == 0) {                        // the evaluator is needed: the request is made behind the loop
+                // THE REQUEST, made here and not behind the loop (the leaf's position would have to live in eight vector registers across the
+                // loop's exit): the leaf's legal moves -- the line tables are the move generator's alone: loaded now, 21 cache lines, and only
+                // by a call that asks -- then the record the evaluator reads.  Every lane-derived value of this block comes from
+                // lane_id_here(): nothing of it can be hoisted above the loop.
+                ADV_LAP(t_sel);
+                load_engine_lines(&lds.T, lane_id_here());
+                __syncthreads();
+                req_k = (uint32_t)wave_request_moves<true>(lds, leaf, leaf_player, A.moves + (size_t)g * REQ_MV);
+                if (lane_id_here() == 0) {
+                    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(A.req + g);
                     q[0] = make_ulonglong2(leaf.occ0, leaf.occ1);
                     q[1] = make_ulonglong2(leaf.a, leaf.b);
                     q[2] = make_ulonglong2(1ULL | ((uint64_t)(uint32_t)depth << 32), (uint64_t)link_off | ((uint64_t)(uint32_t)leaf_player << 32));
+                    q[3] = make_ulonglong2((uint64_t)req_k, 0ULL);
                 }
-                ADV_LAP(t_sel);
-                req_leaf = leaf; req_player = leaf_player;
+                ADV_LAP(t_enc);
                 request = 1;
                 break;
             }
             stop_after = last;                        // (no request: this slot's row of the next evaluator launch is idle)
-            const uint8_t *ob = old + ((uint64_t)shadow << 3);      // expanded there: the evaluator's answer is in that block
-            ev.kind = CCSP_EVAL_CACHED; ev.v_ext = reinterpret_cast<const float *>(ob + 32)[3]; ev.shadow = shadow;
+            ev.kind = CCSP_EVAL_CACHED; ev.v_ext = reinterpret_cast<const float *>(old + ((uint64_t)shadow << 3) + 32)[3]; ev.shadow = shadow;
             a_hits += 1;
         }
         spent += 1;
@@ -1901,16 +2081,11 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
             n_exp += 1;
             ADV_LAP(t_exp);
         }
-        wave_backup(pool, path, mypath, myW, myN, have_stats, depth, terminal, ev.v_ext);
+        wave_backup<true>(pool, path, mypath, myW, myN, have_stats, depth, terminal, ev.v_ext);
         sl.sim += 1;
         __syncthreads();                                  // this simulation's stores before the next one's loads
         ADV_LAP(t_bak);
         if (stop_after) break;
-    }
-    // (3) the request's planes
-    if (request == 1) {
-        wave_encode(lds, req_leaf, req_player, planes + (uint64_t)g * CCSP_PLANES);
-        ADV_LAP(t_enc);
     }
     if (dbg && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -1926,17 +2101,21 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(Params 
         d[16] = r_begin; d[17] = r_end; d[18] = (unsigned long long)spent | ((unsigned long long)request << 32); d[19] = a_depth;
     }
     if (lane == 0) {
-        if (request != 1) P.pend[g].kind = 0;             // nothing asked: the search is done, or the budget is spent
-        if (request && model_sel) model_sel[g] = (uint8_t)(sl.player == 2 ? 1 : 0);    // whose model answers (selfplay.py:30,36,59)
+        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(A.req + g);
+        if (request != 1) {                               // nothing asked: the search is done, the budget is spent, or a walk waits to be resumed
+            q[2] = make_ulonglong2(0ULL, 0ULL);
+            q[3] = make_ulonglong2((uint64_t)left_c << 32, (uint64_t)left_at | ((uint64_t)left_edges << 32));
+        }
+        if (request && A.model_sel) A.model_sel[g] = (uint8_t)(sl.player == 2 ? 1 : 0);    // whose model answers (selfplay.py:30,36,59)
         uint32_t *acc = P.stepacc + (size_t)g * 8;
         acc[0] += a_exp; acc[1] += a_term; acc[2] += a_sims; acc[3] += a_depth; acc[4] += a_children; acc[5] += a_edges; acc[6] += a_hits;
         if (errors) atomicAdd(&P.counters[CCSP_CNT_ERRORS], (unsigned long long)errors);
         if (flags & CCSP_ADVANCE_DEBUG) {                 // diagnostic tallies (tools/bench_free.py --debug): what the slots of this call ended on
             atomicAdd(&P.counters[12], (unsigned long long)(request == 1));                      // ... a request
-            atomicAdd(&P.counters[14], (unsigned long long)(request == 0 && phase == 1));        // ... the budget (idle evaluator row)
+            atomicAdd(&P.counters[14], (unsigned long long)(request == 0 && phase == 1));        // ... the budget / the deadline (idle evaluator row)
         }
     }
-    write_w15(P, g, phase, half, root_shadow);
+    write_w15(P, g, phase, half, root_shadow, fin);
     store_slot_search(P.slots + g, sl);
 }
 
@@ -2003,6 +2182,11 @@ __global__ __launch_bounds__(64) void set_positions_kernel(Params P, const ccsp_
 
 // ---- host side -----------------------------------------------------------------------------------------------
 
+// ccsp_advance's three limits (see ccsp_set_advance_limits below): the process-wide defaults a context starts with
+static int g_advance_budget = 8;
+static int g_advance_time_cap = 5000;    // 10-ns ticks; 0 = none
+static int g_advance_deadline = 8000;    // 10-ns ticks; 0 = none
+
 struct ccsp_ctx {
     ccsp_config cfg;
     Params P;
@@ -2010,6 +2194,7 @@ struct ccsp_ctx {
     uint64_t pool_bytes, path_bytes;
     int phase;                     // stepped path sequencing: 0 idle, 1 begun, 2 root expanded, 3 selected
     int stagger_span;              // CCSP_ADVANCE_STAGGER: ccsp_boundary calls over which the slots' first games begin (0 = cfg.sims)
+    int adv_budget, adv_time_cap, adv_deadline;   // ccsp_advance's limits (ccsp_set_advance_limits; from the process defaults at ccsp_create)
     int opening_plies;             // fused plies played since ccsp_reset while EVERY slot is still in its random opening
                                    // (all games start together); -1 once that is no longer known
 };
@@ -2090,6 +2275,8 @@ static ccsp_ctx *create_on_device(const ccsp_config *cfg, int *err) {
     ctx->cfg = *cfg;
     ctx->phase = 0;
     ctx->opening_plies = -1;
+    ctx->stagger_span = 0;
+    ctx->adv_budget = g_advance_budget; ctx->adv_time_cap = g_advance_time_cap; ctx->adv_deadline = g_advance_deadline;
     CTXCHK(hipSetDevice(cfg->device));
     Params &P = ctx->P;
     const uint64_t G = (uint64_t)cfg->n_slots;
@@ -2332,9 +2519,8 @@ int ccsp_debug_read_slots(ccsp_ctx *ctx, unsigned long long *out /* [n_slots][CC
 // The two times are those of a batch of more than 1024 slots (an evaluator launch of 118 us beside the call); a smaller batch's evaluator
 // launch is shorter (76 us up to 1024 positions, 47 us up to 512: ccsp_net_forward's workgroup shapes) and the times shrink with it
 // (2048 slots in two half-batches: deadline 50 us 14.62 M, 80 us 14.37 M).
-static int g_advance_budget = 8;
-static int g_advance_time_cap = 5000;    // 10-ns ticks; 0 = none
-static int g_advance_deadline = 8000;    // 10-ns ticks; 0 = none
+// Each context has its own three limits (ccsp_set_advance_limits); the process-wide values below are what ccsp_create starts a context
+// with (the ccsp_debug_advance_* hooks change them for contexts created afterwards).
 static int scaled_ticks(int ticks, int n_slots) {
     if (ticks <= 0) return 0;
     const int launch_us = n_slots <= 512 ? 47 : n_slots <= 1024 ? 76 : 120;
@@ -2342,31 +2528,40 @@ static int scaled_ticks(int ticks, int n_slots) {
     return (int)(t < 1 ? 1 : t);
 }
 int ccsp_debug_advance_deadline(int ticks) { const int was = g_advance_deadline; if (ticks >= 0) g_advance_deadline = ticks; return was; }
+int ccsp_set_advance_limits(ccsp_ctx *ctx, int budget, int time_cap_ticks, int deadline_ticks) {
+    if (!ctx) return CCSP_EINVAL;
+    if (budget >= 1) ctx->adv_budget = budget;
+    if (time_cap_ticks >= 0) ctx->adv_time_cap = time_cap_ticks;
+    if (deadline_ticks >= 0) ctx->adv_deadline = deadline_ticks;
+    return CCSP_OK;
+}
 int ccsp_debug_advance_budget(int n) { const int was = g_advance_budget; if (n >= 1) g_advance_budget = n; return was; }
 int ccsp_debug_advance_time_cap(int ticks) { const int was = g_advance_time_cap; if (ticks >= 0) g_advance_time_cap = ticks; return was; }
 
-int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream) {
-    if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD | CCSP_ADVANCE_STAGGER | CCSP_ADVANCE_DEBUG))) return CCSP_EINVAL;
+int ccsp_advance(ccsp_ctx *ctx, const double *pk, const float *v, ccsp_request *req, uint16_t *moves, uint8_t *model_sel, int flags, void *stream) {
+    if (!ctx || !pk || !v || !req || !moves || (flags & ~CCSP_ADVANCE_ALL_FLAGS)) return CCSP_EINVAL;
     if (ctx->cfg.mode != CCSP_MODE_SELFPLAY) return CCSP_EINVAL;          // Game.start's seats are served by the lock-step kernels
     if ((flags & CCSP_ADVANCE_REUSE) && !ctx->P.pool2) return CCSP_ESTATE;  // ccsp_enable_tree_reuse first (an allocation: not inside a captured graph)
     if (ctx->phase != 0) return CCSP_ESTATE;                                // not in the middle of a lock-step ply
     CTX_ENTER(ctx, stream);
-    if (flags & CCSP_ADVANCE_DEBUG)
-        hipLaunchKernelGGL(advance_kernel<true>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget, scaled_ticks(g_advance_time_cap, ctx->P.n_slots), scaled_ticks(g_advance_deadline, ctx->P.n_slots));
-    else
-        hipLaunchKernelGGL(advance_kernel<false>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags, g_advance_budget, scaled_ticks(g_advance_time_cap, ctx->P.n_slots), scaled_ticks(g_advance_deadline, ctx->P.n_slots));
+    AdvArgs a;
+    a.P = ctx->P; a.pk = pk; a.v = v; a.req = reinterpret_cast<Pending *>(req); a.moves = moves; a.model_sel = model_sel;
+    a.flags = flags; a.budget = ctx->adv_budget;
+    a.time_cap = scaled_ticks(ctx->adv_time_cap, ctx->P.n_slots); a.deadline = scaled_ticks(ctx->adv_deadline, ctx->P.n_slots);
+    if (flags & CCSP_ADVANCE_DEBUG) hipLaunchKernelGGL(advance_kernel<true>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(advance_kernel<false>, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, a);
     CCSP_HIPCHK(hipGetLastError());
     ctx->opening_plies = -1;
     return CCSP_OK;
 }
 
-int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream) {
-    if (!ctx || !p || !v || !planes || (flags & ~(CCSP_ADVANCE_REUSE | CCSP_ADVANCE_LOG_GUARD | CCSP_ADVANCE_STAGGER | CCSP_ADVANCE_DEBUG))) return CCSP_EINVAL;
+int ccsp_boundary(ccsp_ctx *ctx, const double *pk, const float *v, ccsp_request *req, uint16_t *moves, uint8_t *model_sel, int flags, void *stream) {
+    if (!ctx || !pk || !v || !req || !moves || (flags & ~CCSP_ADVANCE_ALL_FLAGS)) return CCSP_EINVAL;
     if (ctx->cfg.mode != CCSP_MODE_SELFPLAY) return CCSP_EINVAL;
     if ((flags & CCSP_ADVANCE_REUSE) && !ctx->P.pool2) return CCSP_ESTATE;
     if (ctx->phase != 0) return CCSP_ESTATE;
     CTX_ENTER(ctx, stream);
-    hipLaunchKernelGGL(boundary_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, p, v, planes, model_sel, flags,
+    hipLaunchKernelGGL(boundary_kernel, dim3(ctx->P.n_slots), dim3(64), 0, (hipStream_t)stream, ctx->P, pk, v, reinterpret_cast<Pending *>(req), moves, model_sel, flags,
                        (flags & CCSP_ADVANCE_STAGGER) ? (ctx->stagger_span > 0 ? ctx->stagger_span : ctx->cfg.sims) : 0);
     CCSP_HIPCHK(hipGetLastError());
     ctx->opening_plies = -1;
@@ -2464,13 +2659,17 @@ int ccsp_read_results(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_game_resul
     return CCSP_OK;
 }
 
-// device address of the tree a slot searched last: the first pool, or -- on the free-running path with tree reuse, where consecutive
-// plies alternate between two pools (slot word 15) -- the pool of the search in progress / of the ply just finished
+// device address of the tree a slot FINISHED last: the first pool (fused and lock-step paths: there is no other), or -- on the free-running
+// path, where with tree reuse consecutive plies alternate between two pools -- the pool boundary_kernel recorded in slot word 15 when it
+// ended the ply (bits 10-11).  That record exists only once a free-running ply HAS ended: a context with a second pool that is driven
+// through the lock-step entry points, or has not finished a ply yet, reads the pool of the search in progress (bit 8; 0 until then).
+// With tree reuse the finished tree stays whole while the next ply is searched in the other pool; without, it lasts until the next
+// ply's root is expanded (the answer to the root request).
 static int tree_of_slot(ccsp_ctx *ctx, int slot, const uint8_t **out) {
     uint64_t w15 = 0;
     CCSP_HIPCHK(hipMemcpy(&w15, &ctx->P.slots[slot].w[15], sizeof w15, hipMemcpyDeviceToHost));
     uint32_t half = (uint32_t)((w15 >> 8) & 1);
-    if (ctx->P.pool2 && (w15 & 0xFF) == 0) half ^= 1u;                      // at a ply boundary: the finished ply's tree is in the other pool
+    if ((w15 >> 11) & 1) half = (uint32_t)((w15 >> 10) & 1);
     if (!ctx->P.pool2) half = 0;
     *out = (half ? ctx->P.pool2 : ctx->P.pool) + (uint64_t)slot * ctx->P.pool_stride;
     return CCSP_OK;

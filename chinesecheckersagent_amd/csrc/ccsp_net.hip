@@ -385,10 +385,13 @@ __device__ unsigned long long net_stamps[64];
 #define NET_STAMP(i) do { } while (0)
 #endif
 
-template <typename C>
+// REQ (the free-running path's hand-off, ccsp_net_forward_requests): the input is the batch of REQUEST records -- the position, 64 bytes
+// instead of 1372 of float32 planes: utils.to_model_input (C1) happens in the input phase below -- and the answer is compact: p_out[i][j] =
+// the softmax entry of the j-th legal move of request i (`moves`), CCSP_REQUEST_MOVES doubles per row, k of them written.
+template <typename C, bool REQ>
 __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__restrict__ W, const float *__restrict__ planes, int n,
                                                              float *__restrict__ logits_out, double *__restrict__ p_out,
-                                                             float *__restrict__ v_out) {
+                                                             float *__restrict__ v_out, const uint16_t *__restrict__ moves) {
     constexpr int NB = C::NB, NTH = C::NTH, ROWS = C::ROWS, MT = C::MT, NSPLIT = C::NSPLIT, PADROWS = C::PADROWS, INROWS = C::INROWS,
                   NW = C::NW, F32 = C::F32, F64 = C::F64, M64 = C::M64, XT = C::XT, HB = C::HB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -414,7 +417,30 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     // y1, the zero-halo input of the 3x3 layers (only interior cells are ever written again), is cleared in the same phase
     static_assert((PADROWS * LDY) % 4 == 0, "y1 is cleared 16 bytes at a time");
     for (int i = tid * 4; i < PADROWS * LDY; i += NTH * 4) *reinterpret_cast<f32x4 *>(&S.y1[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr ((NB * 343) % 4 != 0) {                       // (<2, 8>: 686 floats per workgroup, not a multiple of four: the plain way)
+    const ccsp_request *rq = reinterpret_cast<const ccsp_request *>(planes) + s0;      // (REQ)
+    if constexpr (REQ) {
+        // C1 in place: the staging area zeroed, then one thread per (position, checker) writes the checker's id + 1 at the cells it
+        // stands on now / one / two plies ago (ccsp_scatter_checker: the un-swapping of utils.py:135-155), one thread per (position, cell)
+        // the player-two flag (utils.py:157-158).  A row that asks for nothing stays zero.
+        static_assert((INROWS * LDI) % 4 == 0, "the staging area is cleared 16 bytes at a time");
+        for (int i = tid * 4; i < INROWS * LDI; i += NTH * 4) *reinterpret_cast<f32x4 *>(&in[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        struct PlaneWriter {                                   // img[cell * 7 + ch] = val -> in[(s * 49 + cell) * LDI + ch]
+            float *base;
+            struct Ref { float *p; __device__ __forceinline__ void operator=(uint8_t val) const { *p = (float)val; } };
+            __device__ __forceinline__ Ref operator[](int i) const { const int cell = i / 7; return Ref{base + cell * LDI + (i - 7 * cell)}; }
+        };
+        for (int t = tid; t < here * 12; t += NTH) {
+            const int s = t / 12, k = t - 12 * s;
+            if (rq[s].kind == 0) continue;
+            const ccsp_sr st = ccsp_load_sr(&rq[s].state);
+            ccsp_scatter_checker(st, (int)rq[s].player, k, PlaneWriter{in + s * 49 * LDI});
+        }
+        for (int t = tid; t < here * 49; t += NTH) {
+            const int s = t / 49, cell = t - 49 * s;
+            if (rq[s].kind != 0 && rq[s].player == 2) in[(s * 49 + cell) * LDI + 6] = 1.0f;
+        }
+    } else if constexpr ((NB * 343) % 4 != 0) {                // (<2, 8>: 686 floats per workgroup, not a multiple of four: the plain way)
         for (int i = tid; i < INROWS * LDI; i += NTH) {
             const int cellg = i / LDI, ch = i % LDI, s = cellg / 49, cell = cellg % 49;
             in[i] = (ch < 7 && s < here) ? planes[(s0 + s) * 343 + cell * 7 + ch] : 0.0f;
@@ -717,7 +743,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         const float *w2 = W + LAY.f2_w;
         float acc = W[LAY.f2_b];
         for (int u = 0; u < 32; u++) acc += h1[tid * 32 + u] * w2[u];
-        v_out[s0 + tid] = tanhf(acc);
+        if (!REQ || rq[tid].kind != 0) v_out[s0 + tid] = tanhf(acc);
     }
     // ---- logits out + float64 softmax (utils.softmax, utils.py:187-192): one position per wave ---
     for (int s = wave; s < here; s += NTH / 64) {
@@ -734,6 +760,28 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             sum += e[j];
         }
         for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+        if constexpr (REQ) {
+            // the compact answer: the float64 softmax entries of the request's k legal moves, in the order of its move row.  Every lane
+            // forms its five entries as before (the same e / sum), leaves them in LDS (the trunk buffer is dead; 296 doubles per wave) and
+            // lane j picks entry moves[j]: DS operations of one wave complete in order, no barrier needed.
+            double *pd = reinterpret_cast<double *>(S.x) + wave * 296;
+            if (rq[s].kind != 0) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const int i = lane + 64 * j;
+                    if (i < NPOL) pd[i] = e[j] / sum;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int k = (int)rq[s].k;
+                const uint16_t *mrow = moves + (s0 + s) * CCSP_REQUEST_MOVES;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int j = lane + 64 * h;
+                    if (j < k) p_out[(s0 + s) * CCSP_REQUEST_MOVES + j] = pd[mrow[j] & 0x1FF];
+                }
+                __builtin_amdgcn_wave_barrier();                // (the next position of this wave overwrites pd)
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 5; j++) {
             const int i = lane + 64 * j;
@@ -741,6 +789,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 if (p_out) p_out[(s0 + s) * NPOL + i] = e[j] / sum;
                 if (logits_out) logits_out[(s0 + s) * NPOL + i] = row[i];
             }
+        }
         }
     }
     NET_STAMP(31);
@@ -762,18 +811,19 @@ void pack_gemm(const std::vector<float> &Wkn, int K, int N, int KB, int NT, floa
 
 }  // namespace
 
-template <typename C>
-static int launch_net(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream, bool *attr_set) {
+template <typename C, bool REQ = false>
+static int launch_net(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream, bool *attr_set,
+                      const uint16_t *moves = nullptr) {
     // the dynamic-LDS opt-in is a per-device property of the kernel: once per device ordinal, not per process
     int dev = 0;
     CCSP_HIPCHK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        CCSP_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(net_forward_kernel<C>),
+        CCSP_HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(net_forward_kernel<C, REQ>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<C>)));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int grid = (n + C::NB - 1) / C::NB;
-    hipLaunchKernelGGL(net_forward_kernel<C>, dim3(grid), dim3(C::NTH), sizeof(Smem<C>), (hipStream_t)stream, packed, planes, n, logits, p, v);
+    hipLaunchKernelGGL((net_forward_kernel<C, REQ>), dim3(grid), dim3(C::NTH), sizeof(Smem<C>), (hipStream_t)stream, packed, planes, n, logits, p, v, moves);
     CCSP_HIPCHK(hipGetLastError());
     return CCSP_OK;
 }
@@ -857,6 +907,17 @@ int ccsp_net_forward(const float *packed, const float *planes, int n, float *log
     if (shape == 2) return launch_net<Cfg<2, 8>>(packed, planes, n, logits, p, v, stream, attr2);
     if (shape == 4) return launch_net<Cfg<4, 4>>(packed, planes, n, logits, p, v, stream, attr4);
     return launch_net<Cfg<8, 8>>(packed, planes, n, logits, p, v, stream, attr8);
+}
+
+int ccsp_net_forward_requests(const float *packed, const ccsp_request *req, const uint16_t *moves, int n, double *pk, float *v, void *stream) {
+    if (n < 0 || (n > 0 && (!packed || !req || !moves || !pk || !v))) return CCSP_EINVAL;
+    if (n == 0) return CCSP_OK;
+    static bool attr8[64] = {false}, attr4[64] = {false}, attr2[64] = {false};
+    const float *in = reinterpret_cast<const float *>(req);
+    const int shape = g_net_shape ? g_net_shape : (n <= CCSP_NET_TINY ? 2 : (n <= CCSP_NET_SMALL ? 4 : 8));
+    if (shape == 2) return launch_net<Cfg<2, 8>, true>(packed, in, n, nullptr, pk, v, stream, attr2, moves);
+    if (shape == 4) return launch_net<Cfg<4, 4>, true>(packed, in, n, nullptr, pk, v, stream, attr4, moves);
+    return launch_net<Cfg<8, 8>, true>(packed, in, n, nullptr, pk, v, stream, attr8, moves);
 }
 
 #ifdef CCSP_STAMPS

@@ -340,6 +340,9 @@ constexpr int ENC_STATES = 64;      // states per workgroup: 64 * 343 B image = 
 
 // C1: the 12 checkers of each state scatter their id+1 into a zeroed byte image in LDS (one lane per
 // checker), then the workgroup converts bytes to float and streams 16-byte stores.
+// REQ: the positions are the records of the free-running path's request buffer (ccsp_request: state at +0, kind at +32, player at +44);
+// a record that asks for nothing (kind 0) gives an all-zero row
+template <bool REQ>
 __global__ __launch_bounds__(ENC_THREADS) void encode_kernel(const ccsp_state *__restrict__ states,
                                                              const uint8_t *__restrict__ player, int n,
                                                              float *__restrict__ planes) {
@@ -353,8 +356,12 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_kernel(const ccsp_state *_
     __syncthreads();
     for (int t = tid; t < here * 12; t += ENC_THREADS) {
         const int sl = t / 12, k = t % 12;
-        const ccsp_sr a = ccsp_load_sr(states + base + sl);
-        const int pl = player[base + sl];
+        ccsp_sr a; int pl;
+        if (REQ) {
+            const ccsp_request *r = reinterpret_cast<const ccsp_request *>(states) + base + sl;
+            if (r->kind == 0) { if (k == 0) p2flag[sl] = 0; continue; }
+            a = ccsp_load_sr(&r->state); pl = (int)r->player;
+        } else { a = ccsp_load_sr(states + base + sl); pl = player[base + sl]; }
         ccsp_scatter_checker(a, pl, k, &img[sl * CCSP_PLANES]);
         if (k == 0) p2flag[sl] = (pl == 2);
     }
@@ -373,6 +380,29 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_kernel(const ccsp_state *_
         if (e + 3 < total) *reinterpret_cast<float4 *>(dst + e) = make_float4(v[0], v[1], v[2], v[3]);
         else for (int j = 0; j < 4 && e + j < total; j++) dst[e + j] = v[j];
     }
+}
+
+// the compact answer of the free-running path from a full policy row: one workgroup per request, one lane per legal move
+__global__ __launch_bounds__(CCSP_REQUEST_MOVES) void gather_priors_kernel(const ccsp_request *__restrict__ req, const uint16_t *__restrict__ moves,
+                                                                           const double *__restrict__ p, double *__restrict__ pk) {
+    const int i = blockIdx.x, j = threadIdx.x;
+    if (req[i].kind == 0 || j >= (int)req[i].k) return;
+    pk[(size_t)i * CCSP_REQUEST_MOVES + j] = p[(size_t)i * CCSP_NUM_ACTIONS + (moves[(size_t)i * CCSP_REQUEST_MOVES + j] & 0x1FF)];
+}
+
+// test hook: spec.hash_eval / forward_eval / the uniform stub (the fused path's built-in evaluators) answering requests
+__global__ __launch_bounds__(CCSP_REQUEST_MOVES) void table_eval_kernel(int evaluator, const ccsp_request *__restrict__ req, const uint16_t *__restrict__ moves,
+                                                                        double *__restrict__ pk, float *__restrict__ v) {
+    const int i = blockIdx.x, j = threadIdx.x;
+    if (req[i].kind == 0) return;
+    const ccsp_sr st = ccsp_load_sr(&req[i].state);
+    const int player = (int)req[i].player;
+    const uint64_t key = evaluator == CCSP_EVAL_HASH ? ccsp_state_key(st, player) : 0;
+    if (j == 0) v[i] = evaluator == CCSP_EVAL_HASH ? ccsp_hash_value(key) : (evaluator == CCSP_EVAL_FORWARD ? ccsp_forward_value(st, player) : 0.0f);
+    if (j >= (int)req[i].k) return;
+    const int idx = moves[(size_t)i * CCSP_REQUEST_MOVES + j] & 0x1FF;
+    pk[(size_t)i * CCSP_REQUEST_MOVES + j] = evaluator == CCSP_EVAL_HASH ? ccsp_hash_prior(key, idx)
+                                            : (evaluator == CCSP_EVAL_FORWARD ? ccsp_forward_prior(st, player, idx / CCSP_NCELL, idx % CCSP_NCELL) : 1.0 / 294.0);
 }
 
 int g_cap = MG_STACK;                 // stack entries a lane may use (test hook below; MG_STACK in production)
@@ -430,7 +460,32 @@ int ccsp_step(const ccsp_state *in, const uint8_t *player, const uint8_t *mv, in
 int ccsp_encode(const ccsp_state *s, const uint8_t *player, int n, float *planes, void *stream) {
     if (n < 0 || (n > 0 && (!s || !player || !planes))) return CCSP_EINVAL;
     if (n == 0) return CCSP_OK;
-    hipLaunchKernelGGL(encode_kernel, dim3((n + ENC_STATES - 1) / ENC_STATES), dim3(ENC_THREADS), 0, (hipStream_t)stream, s, player, n, planes);
+    hipLaunchKernelGGL(encode_kernel<false>, dim3((n + ENC_STATES - 1) / ENC_STATES), dim3(ENC_THREADS), 0, (hipStream_t)stream, s, player, n, planes);
+    CCSP_HIPCHK(hipGetLastError());
+    return CCSP_OK;
+}
+
+int ccsp_encode_requests(const ccsp_request *req, int n, float *planes, void *stream) {
+    if (n < 0 || (n > 0 && (!req || !planes))) return CCSP_EINVAL;
+    if (n == 0) return CCSP_OK;
+    hipLaunchKernelGGL(encode_kernel<true>, dim3((n + ENC_STATES - 1) / ENC_STATES), dim3(ENC_THREADS), 0, (hipStream_t)stream,
+                       reinterpret_cast<const ccsp_state *>(req), (const uint8_t *)nullptr, n, planes);
+    CCSP_HIPCHK(hipGetLastError());
+    return CCSP_OK;
+}
+
+int ccsp_gather_priors(const ccsp_request *req, const uint16_t *moves, const double *p, int n, double *pk, void *stream) {
+    if (n < 0 || (n > 0 && (!req || !moves || !p || !pk))) return CCSP_EINVAL;
+    if (n == 0) return CCSP_OK;
+    hipLaunchKernelGGL(gather_priors_kernel, dim3(n), dim3(CCSP_REQUEST_MOVES), 0, (hipStream_t)stream, req, moves, p, pk);
+    CCSP_HIPCHK(hipGetLastError());
+    return CCSP_OK;
+}
+
+int ccsp_debug_table_eval(int evaluator, const ccsp_request *req, const uint16_t *moves, int n, double *pk, float *v, void *stream) {
+    if (n < 0 || evaluator < CCSP_EVAL_UNIFORM || evaluator > CCSP_EVAL_FORWARD || (n > 0 && (!req || !moves || !pk || !v))) return CCSP_EINVAL;
+    if (n == 0) return CCSP_OK;
+    hipLaunchKernelGGL(table_eval_kernel, dim3(n), dim3(CCSP_REQUEST_MOVES), 0, (hipStream_t)stream, evaluator, req, moves, pk, v);
     CCSP_HIPCHK(hipGetLastError());
     return CCSP_OK;
 }

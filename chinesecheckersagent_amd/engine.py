@@ -41,7 +41,7 @@ class SelfPlayEngine(object):
         self.ctx = self.L.ccsp_create(C.byref(cfg), C.byref(err))
         if not self.ctx:
             check(err.value or _lib.EHIP, 'ccsp_create')
-        self.first_game, self.game_stride = int(first_game), int(game_stride)
+        self.first_game, self.game_stride, self.device = int(first_game), int(game_stride), int(device)
 
     def close(self):
         if getattr(self, 'ctx', None):
@@ -102,19 +102,42 @@ class SelfPlayEngine(object):
         """boundary(stagger=True): the number of boundary calls over which the slots' first games begin (default: `sims`)"""
         check(self.L.ccsp_set_stagger_span(self.ctx, int(min(boundary_calls, 65535))), 'ccsp_set_stagger_span')
 
-    def advance(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stream=None, debug=False):
-        """slots in a search: take the answer (p, v) to the leaf they asked about, go on to their next request (planes out)"""
-        self._check_pv(p, v)
-        flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0) | (8 if debug else 0)
-        check(self.L.ccsp_advance(self.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(),
+    def request_buffers(self):
+        """the caller-owned hand-off buffers of the free-running path, zero-filled: (req [n_slots, 64] uint8 = ccsp_request records,
+        moves [n_slots, 128] int16 = the requests' legal moves, pk [n_slots, 128] float64 = a compact answer to start with, v [n_slots])"""
+        import torch
+        dev = torch.device('cuda', self.device)
+        return (torch.zeros((self.n_slots, 64), dtype=torch.uint8, device=dev),
+                torch.zeros((self.n_slots, _lib.REQUEST_MOVES), dtype=torch.int16, device=dev),
+                torch.zeros((self.n_slots, _lib.REQUEST_MOVES), dtype=torch.float64, device=dev),
+                torch.zeros(self.n_slots, dtype=torch.float32, device=dev))
+
+    def set_advance_limits(self, budget=-1, time_cap=-1, deadline=-1):
+        """this context's limits of ccsp_advance (ticks of 10 ns; a negative value leaves that one alone)"""
+        check(self.L.ccsp_set_advance_limits(self.ctx, int(budget), int(time_cap), int(deadline)), 'ccsp_set_advance_limits')
+
+    def advance(self, pk, v, req, moves, model_sel=None, reuse=False, log_guard=False, stream=None, debug=False):
+        """slots in a search: take the compact answer (pk, v) to the leaf they asked about, go on to their next request (req, moves out)"""
+        self._check_hand_off(pk, v, req, moves)
+        flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0) | (_lib.ADVANCE_DEBUG if debug else 0)
+        check(self.L.ccsp_advance(self.ctx, pk.data_ptr(), v.data_ptr(), req.data_ptr(), moves.data_ptr(),
                                   model_sel.data_ptr() if model_sel is not None else None, flags, _stream_ptr(stream)), 'ccsp_advance')
 
-    def boundary(self, p, v, planes, model_sel=None, reuse=False, log_guard=False, stagger=False, stream=None, debug=False):
+    def boundary(self, pk, v, req, moves, model_sel=None, reuse=False, log_guard=False, stagger=False, stream=None, debug=False, overlapped=False):
         """slots between two searches: root expansion from the answer, or the finished ply's move and rules and the next ply's root"""
-        self._check_pv(p, v)
-        flags = (_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0) | (_lib.ADVANCE_STAGGER if stagger else 0) | (8 if debug else 0)
-        check(self.L.ccsp_boundary(self.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(),
+        self._check_hand_off(pk, v, req, moves)
+        flags = ((_lib.ADVANCE_REUSE if reuse else 0) | (_lib.ADVANCE_LOG_GUARD if log_guard else 0) | (_lib.ADVANCE_STAGGER if stagger else 0) |
+                 (_lib.ADVANCE_DEBUG if debug else 0) | (_lib.ADVANCE_OVERLAPPED if overlapped else 0))
+        check(self.L.ccsp_boundary(self.ctx, pk.data_ptr(), v.data_ptr(), req.data_ptr(), moves.data_ptr(),
                                    model_sel.data_ptr() if model_sel is not None else None, flags, _stream_ptr(stream)), 'ccsp_boundary')
+
+    def _check_hand_off(self, pk, v, req, moves):
+        import torch
+        n, m = self.n_slots, _lib.REQUEST_MOVES
+        assert pk.is_cuda and pk.dtype == torch.float64 and pk.is_contiguous() and pk.numel() == n * m
+        assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and v.numel() == n
+        assert req.is_cuda and req.dtype == torch.uint8 and req.is_contiguous() and req.numel() == n * 64
+        assert moves.is_cuda and moves.dtype == torch.int16 and moves.is_contiguous() and moves.numel() == n * m
 
     def _check_pv(self, p, v):
         import torch

@@ -81,6 +81,8 @@ def init_rank(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     from ._lib import prefer_blocking_sync
+    from .selfplay import tune_host_allocator
+    tune_host_allocator()                                 # a rank process is this library's own: its heap keeps its pages (selfplay.py)
     prefer_blocking_sync(local)                           # before the first GPU call of the rank: waits sleep instead of spinning
     torch.cuda.set_device(local)
     dist = None

@@ -223,9 +223,50 @@ class ResidualCNN(Model):
         logits, v = self.predict_batch(x)
         return torch.softmax(logits.double(), dim=-1).contiguous(), v.float().contiguous()
 
+    def evaluate_requests(self, req, moves, pk=None, v=None):
+        """The free-running path's evaluator call (ccsp_advance / ccsp_boundary of include/ccsp.h): req [n, 64] uint8 = ccsp_request
+        records, moves [n, 128] int16 = their legal moves -> (pk [n, 128] float64: the softmax entries of those moves, v [n] float32).
+        backend 'hip': ONE launch of the fused kernel, which builds the planes from the 32-byte positions itself and writes the compact
+        answer (ccsp_net_forward_requests); otherwise planes out (ccsp_encode_requests), the module, and a gather."""
+        torch = _torch()
+        n = req.shape[0]
+        if pk is None:
+            pk = torch.empty((n, moves.shape[1]), dtype=torch.float64, device=req.device)
+        if v is None:
+            v = torch.empty(n, dtype=torch.float32, device=req.device)
+        if self.backend == 'hip':
+            from . import _lib
+            from .engine import _stream_ptr
+            _lib.check(_lib.lib().ccsp_net_forward_requests(self._ensure_packed().data_ptr(), req.data_ptr(), moves.data_ptr(), n,
+                                                            pk.data_ptr(), v.data_ptr(), _stream_ptr()), 'ccsp_net_forward_requests')
+            return pk, v
+        return evaluate_requests_with(self.evaluate_batch, req, moves, pk, v)
+
     # ---- model.py:21-24
     def predict(self, input_board):
         torch = _torch()
         x = torch.from_numpy(np.asarray(input_board, dtype=np.float32)[None]).to(self.device)
         p, v = self.evaluate_batch(x)
         return p[0].cpu().numpy(), np.asarray(v[0].cpu().numpy(), dtype=np.float32)
+
+
+def evaluate_requests_with(evaluate_batch, req, moves, pk=None, v=None):
+    """requests -> compact answers through ANY planes evaluator (`evaluate_batch(x [n,7,7,7] f32 cuda) -> (p f64 [n,294], v f32 [n])`):
+    ccsp_encode_requests (utils.to_model_input of every request, zeros where nothing is asked), the evaluator, ccsp_gather_priors
+    (pk[i][j] = p[i][action index of move j]).  What the PyTorch-module backend and reference-style `.predict` objects run on."""
+    from . import _lib
+    from .engine import _stream_ptr
+    torch = _torch()
+    n = req.shape[0]
+    planes = torch.empty((n, 7, 7, 7), dtype=torch.float32, device=req.device)
+    L = _lib.lib()
+    _lib.check(L.ccsp_encode_requests(req.data_ptr(), n, planes.data_ptr(), _stream_ptr()), 'ccsp_encode_requests')
+    p, vv = evaluate_batch(planes)
+    p = p.contiguous()
+    if pk is None:
+        pk = torch.empty((n, moves.shape[1]), dtype=torch.float64, device=req.device)
+    _lib.check(L.ccsp_gather_priors(req.data_ptr(), moves.data_ptr(), p.data_ptr(), n, pk.data_ptr(), _stream_ptr()), 'ccsp_gather_priors')
+    if v is None:
+        return pk, vv.float().contiguous()
+    v.copy_(vv)
+    return pk, v

@@ -86,6 +86,38 @@ def _warn(msg):
     sys.stderr.write('chinesecheckersagent_amd: ' + msg + '\n')
 
 
+def _check_hot_path(model1, model2, n_slots, free_running):
+    """The delivered path is the hand-written one: a CUDA float32 ResidualCNN on the fused HIP kernel (backend 'hip'), and from 1024
+    slots on the free-running kernels.  A model that would silently leave it -- backend='torch' / precision='fp64' (MIOpen modules), a
+    wrapped model without the batched interface at a batch size where that matters, free_running=False forced at >= 1024 slots -- is
+    reported once on stderr and is an ERROR under CCSP_STRICT=1 (bench.py sets it).  Reference-style `.predict`
+    objects at small sizes (plumbing tests, selfplay.py:155-175) are what they are and pass."""
+    problems = []
+    for name, m in (('model1', model1), ('model2', model2)):
+        if m is None:
+            continue
+        backend, device = getattr(m, 'backend', None), getattr(m, 'device', None)
+        if backend is not None and getattr(device, 'type', None) == 'cuda' and backend != 'hip':
+            problems.append("%s runs on backend=%r, precision=%r: the PyTorch modules, not the fused HIP kernel (ResidualCNN(precision='fp32', "
+                            "backend='auto') is the delivered evaluator)" % (name, backend, getattr(m, 'precision', None)))
+        if backend is None and n_slots >= 1024:
+            problems.append('%s has no batched evaluator (a reference-style .predict object): %d slots would be evaluated one position at a '
+                            'time on the host' % (name, n_slots))
+    if free_running is False and n_slots >= 1024:
+        problems.append('free_running=False with %d slots: the lock-step kernels, not the free-running path bench.py measures' % n_slots)
+    if not problems:
+        return
+    msg = 'SelfPlayRun leaves the delivered hot path: ' + '; '.join(problems)
+    if _strict():
+        raise _lib.CcspError(msg + ' (CCSP_STRICT=1)')
+    if msg not in _warned:
+        _warned.add(msg)
+        _warn(msg)
+
+
+_warned = set()
+
+
 class BatchSelfPlay(object):
     """n_slots concurrent games through the stepped path (external evaluator).
 
@@ -132,8 +164,9 @@ class BatchSelfPlay(object):
             if self.reuse:
                 self.eng.enable_tree_reuse()
             self._model_sel = torch.zeros(n_slots, dtype=torch.uint8, device=dev) if self.m2 is not None else None
-            self._p0 = torch.zeros((n_slots, NUM_ACTIONS), dtype=torch.float64, device=dev)     # the first call's answer to no request
-            self._v0 = torch.zeros(n_slots, dtype=torch.float32, device=dev)
+            # the hand-off of the free-running path (include/ccsp.h): request records + their move lists out, compact answers in;
+            # _p0 / _v0: the first call's answer to no request
+            self._req, self._moves, self._p0, self._v0 = self.eng.request_buffers()
             self._started = False
             self._round_no = 0
             self.net_events = None                         # bench.py: [(start, end)] HIP events around the evaluator launch of the plain (uncaptured) steps
@@ -194,10 +227,17 @@ class BatchSelfPlay(object):
     SIDE_STREAM = False      # ccsp_boundary on a stream of its own beside the next evaluator launch (measured: hipGraphs with forks
                              # stop overlapping the two half-batches' graphs; kept for experiments)
 
+    def _answer(self, m):
+        """(pk, v): model m's compact answers to the requests on the table"""
+        if hasattr(m, 'evaluate_requests'):
+            return m.evaluate_requests(self._req, self._moves)
+        from .model import evaluate_requests_with
+        return evaluate_requests_with(m.evaluate_batch, self._req, self._moves)
+
     def _evaluate_free(self):
-        p, v = self.m1.evaluate_batch(self.planes)
+        p, v = self._answer(self.m1)
         if self.m2 is not None:                            # the request names the model: player two's searches ask model2 (selfplay.py:30,36,59)
-            p2, v2 = self.m2.evaluate_batch(self.planes)
+            p2, v2 = self._answer(self.m2)
             sel = self._model_sel.bool()
             p = self.torch.where(sel[:, None], p2, p)
             v = self.torch.where(sel, v2, v)
@@ -209,17 +249,18 @@ class BatchSelfPlay(object):
         ply is long -- pi, sampling, rules, Dirichlet noise -- and runs beside the NEXT evaluator launch instead of in front of it)"""
         torch, e = self.torch, self.eng
         if not self.SIDE_STREAM:
-            e.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, debug=self.DEBUG)
+            e.advance(p, v, self._req, self._moves, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, debug=self.DEBUG)
             self._round_no += 1
             if self._round_no % (self.BOUNDARY_EVERY if self.n_slots >= 1024 else 1) == 0:      # (a small batch is latency-bound: no waiting there)
-                e.boundary(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, stagger=self.stagger, debug=self.DEBUG)
+                e.boundary(p, v, self._req, self._moves, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, stagger=self.stagger, debug=self.DEBUG)
             return
         cur = torch.cuda.current_stream()
         cur.wait_stream(self._side)                        # the previous round's boundary work: done before this round's advance
-        e.advance(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, debug=self.DEBUG)
+        e.advance(p, v, self._req, self._moves, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, debug=self.DEBUG)
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
-            e.boundary(p, v, self.planes, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, stagger=self.stagger, debug=self.DEBUG)
+            e.boundary(p, v, self._req, self._moves, self._model_sel, reuse=self.reuse, log_guard=self.log_guard, stagger=self.stagger, debug=self.DEBUG,
+                       overlapped=True)
         if not capturing:
             p.record_stream(self._side)
             v.record_stream(self._side)
@@ -607,10 +648,16 @@ class SelfPlayRun(object):
 
     def __init__(self, model1, model2=None, n_games=1, sims=MCTS_SIMULATIONS, seed=None, randomised=False, first_game=0,
                  game_stride=1, device=0, max_slots=MAX_SLOTS, harvest_every=HARVEST_EVERY, use_graph=True, keep_records=True,
-                 sink=None, n_parts=None, free_running=None, reuse=None, stagger_span=None):
-        tune_host_allocator()
-        _lib.prefer_blocking_sync()                        # (effective when the process has not touched the GPU yet)
+                 sink=None, n_parts=None, free_running=None, reuse=None, stagger_span=None, off_path_ok=False):
+        # (host allocator tuning is the PROCESS's business: the rank entry points -- worker.py, bench.py -- call tune_host_allocator();
+        # an embedding process opts in with CCSP_MALLOPT=1)
+        import os
+        if os.environ.get('CCSP_MALLOPT') == '1':
+            tune_host_allocator()
+        _lib.prefer_blocking_sync(device)                  # (this run's device; effective when the process has not touched it yet)
         n_games = int(n_games)
+        if not off_path_ok:                                # (off_path_ok: a deliberate comparison, e.g. bench.py's lock-step variant)
+            _check_hot_path(model1, model2, min(n_games, int(max_slots)), free_running)
         n_slots = max(1, min(n_games, int(max_slots)))
         if n_parts is None:
             # two half-batches from 1024 slots on (measured in steady state at 400 simulations, M node-expansions/s, one part lock-step /

@@ -17,6 +17,7 @@ ranks (the step is the one a single GPU takes on the whole batch, moving statist
 Weights are read from and written to the reference's own `versionNNNN-weights.h5` layout (h5lite).
 """
 import os
+import time
 
 import numpy as np
 
@@ -245,10 +246,15 @@ class Trainer(object):
         quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
         if quiet is not None:
             quiet(False)                               # (the warm-up runs on a side stream on purpose)
+        t_first = time.time()
         try:
             with torch.cuda.stream(side):
                 for _ in range(3):
                     self.step(self._gx, self._gpi, self._gz)
+            side.synchronize()
+            # (the first of them carries the process's lazy initialisation: MIOpen's choice -- on a fresh machine, BUILD -- of the
+            # convolution kernels of this net's 31 layer shapes, forward and backward; seconds on a cold kernel cache, none on a warm one)
+            self.fit_timings['first_steps_s'] = time.time() - t_first
         except BaseException:
             if quiet is not None:
                 quiet(True)
@@ -264,6 +270,7 @@ class Trainer(object):
                         if torch.is_tensor(v):
                             v.copy_(opt_keep[id(p_)][k]) if (had_state and id(p_) in opt_keep and k in opt_keep[id(p_)]) else v.zero_()
         self.net.train()
+        t_cap = time.time()
         try:
             g = torch.cuda.CUDAGraph()
             self.opt.zero_grad(set_to_none=True)
@@ -275,6 +282,7 @@ class Trainer(object):
         finally:
             if quiet is not None:
                 quiet(True)                            # the warning is back on whether the capture worked or not
+        self.fit_timings['capture_s'] = time.time() - t_cap
         self._graph, self._graph_loss, self._graph_bs = g, total, batch_size
 
     def fit(self, board_x, pi_y, v_y, batch_size=BATCH_SIZE, epochs=EPOCHS, validation_split=0.05, seed=0, use_graph=True):
@@ -282,6 +290,10 @@ class Trainer(object):
         rest is reshuffled every epoch; returns per-epoch (train loss, val loss).  On one GPU the full batches are replays of a
         captured hipGraph of the step (_capture_step); a ragged last batch, DistributedDataParallel and the CPU run eagerly."""
         torch = self.torch
+        # wall seconds of this call by phase (bench.py's config 5 reports them): host -> device copies, the three throw-away steps in
+        # front of the capture (lazy initialisation), the capture itself, the epochs
+        self.fit_timings = {'to_device_s': 0.0, 'first_steps_s': 0.0, 'capture_s': 0.0, 'epochs_s': 0.0, 'steps': 0, 'graph': False}
+        t_fit = time.time()
         x = torch.as_tensor(np.asarray(board_x), dtype=torch.float32)
         pi = torch.as_tensor(np.asarray(pi_y), dtype=torch.float32)
         z = torch.as_tensor(np.asarray(v_y), dtype=torch.float32)
@@ -289,6 +301,9 @@ class Trainer(object):
         split = int(n * (1.0 - validation_split))
         xt, pt, zt = x[:split].to(self.device), pi[:split].to(self.device), z[:split].to(self.device)
         xv, pv, zv = x[split:].to(self.device), pi[split:].to(self.device), z[split:].to(self.device)
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
+        self.fit_timings['to_device_s'] = time.time() - t_fit
         gen = torch.Generator().manual_seed(seed)
         hist = []
         graph = None
@@ -303,9 +318,12 @@ class Trainer(object):
                 if _strict():
                     raise
                 _warn('hipGraph capture of the training step failed (%r): eager steps' % (ex,))
+        self.fit_timings['graph'] = graph is not None
+        t_ep = time.time()
         for _ in range(epochs):
             perm = torch.randperm(split, generator=gen).to(self.device)
             tot, cnt = 0.0, 0
+            self.fit_timings['steps'] += (split + batch_size - 1) // batch_size
             tot_dev = torch.zeros((), dtype=torch.float64, device=self.device) if graph is not None else None
             if graph is not None:                       # the epoch's rows in their shuffled order, gathered once: a step is three copies + a replay
                 xe, pe, ze = xt[perm], pt[perm], zt[perm]
@@ -339,7 +357,26 @@ class Trainer(object):
             if tot_dev is not None:
                 tot += float(tot_dev)
             hist.append((tot / max(cnt, 1), val))
+        self.fit_timings['epochs_s'] = time.time() - t_ep          # (the float(...) read-backs above have synchronised)
         return hist
+
+
+last_fit_timings = {}          # Trainer.fit_timings of the last train() call of this process
+
+
+def warm_up(device=None, batch_size=BATCH_SIZE):
+    """The process's lazy initialisation of the training step, on its own: a throw-away Trainer takes the three steps in front of a
+    capture (MIOpen chooses -- on a machine with a cold kernel cache, BUILDS -- the forward and backward kernels of the net's layer
+    shapes) and captures the step graph once.  Seconds on a fresh machine (measured on fresh GPU boxes: ~5 s of an 11-s first fit), a
+    fraction of one afterwards; a loop that wants its first iteration's `train` to cost what every later one costs calls this first.
+    -> wall seconds."""
+    t0 = time.time()
+    t = Trainer(device=device)
+    if t.device.type == 'cuda':
+        t.fit_timings = {}
+        t._capture_step(batch_size)
+        t.torch.cuda.synchronize(t.device)
+    return time.time() - t0
 
 
 def train(model_path, board_x, pi_y, v_y, data_retention, version, save_dir=SAVE_WEIGHTS_DIR, device=None, seed=0, ddp=False):
@@ -357,6 +394,8 @@ def train(model_path, board_x, pi_y, v_y, data_retention, version, save_dir=SAVE
     keep = rng.choice(n, int(data_retention * n), replace=False)
     bx, py, vy = np.asarray(board_x)[keep], np.asarray(pi_y)[keep], np.asarray(v_y)[keep]
     t.fit(bx, py, vy, seed=seed)
+    last_fit_timings.clear()
+    last_fit_timings.update(t.fit_timings)             # (evolve reports them: bench.py's config 5)
     if not ddp:
         return t.save_weights(save_dir, MODEL_PREFIX, version)
     import torch.distributed as dist
@@ -538,6 +577,12 @@ def evolve(cur_model_path, other_opponent_for_selfplay=None, iteration_count=0, 
         cur_model_path = train(cur_model_path, board_x, pi_y, v_y, retention, iteration_count, save_dir=weights_dir,
                                device='cuda:%d' % device if dist is not None else None, ddp=dist is not None)
         tm['train_s'] = time.time() - t0
+        # where train_s goes: the fit's lazy initialisation (first steps: MIOpen picks -- on a cold cache builds -- its kernels), the
+        # capture of the step graph, the epochs themselves; the rest is loading / saving weights and the retention draw
+        tm['train_first_steps_s'] = last_fit_timings.get('first_steps_s', 0.0)
+        tm['train_capture_s'] = last_fit_timings.get('capture_s', 0.0)
+        tm['train_epochs_s'] = last_fit_timings.get('epochs_s', 0.0)
+        tm['train_steps'] = last_fit_timings.get('steps', 0)
         # evaluate (train.py:308-314)
         if best_model is not None:
             t0 = time.time()

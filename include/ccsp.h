@@ -244,18 +244,35 @@ int ccsp_expand_backup_select(ccsp_ctx *ctx, const double *p, const float *v, fl
 int ccsp_ply_end(ccsp_ctx *ctx, void *stream);
 
 /* Free-running stepped path (self-play mode): the same search, every slot at its own simulation of its own ply.  The caller's loop is
- *     for ever: [evaluate planes -> (p, v)]  ->  ccsp_advance(p, v)  ->  ccsp_boundary(p, v)
- * (the very first round has no answer to give: any p, v).  Per slot, a call takes the answer to the request the slot left earlier and
- * goes on until it needs the evaluator again -- planes[slot] out, request recorded:
+ *     for ever: [evaluate the requests -> (pk, v)]  ->  ccsp_advance(pk, v, req, moves)  ->  ccsp_boundary(pk, v, req, moves)
+ * (the very first round has no answer to give: any pk, v).  Per slot, a call takes the answer to the request the slot left earlier and
+ * goes on until it needs the evaluator again -- request record and move list out -- :
  *   ccsp_advance    slots in a search: expansion + backup of the answered leaf (MCTS.py:93-118), then selection (MCTS.py:49-76) --
  *                   and on through simulations that end in a won leaf (MCTS.py:81-90) and through reused positions -- until a leaf needs
  *                   the evaluator, or the ply's `sims` simulations are done;
  *   ccsp_boundary   slots between two searches: root expansion + Dirichlet noise from the answer (selfplay.py:117-124), or: pi, the move,
  *                   the end-of-ply rules and the log row of the finished ply (MCTS.py:127-153, selfplay.py:38-74), one opening ply
- *                   (selfplay.py:83-104), the next ply's root -- expanded from the previous tree (reuse) or its planes out as a request.
- *                   It may run on ANOTHER stream beside the next evaluator launch, provided it starts after the ccsp_advance of its round
- *                   and ends before the ccsp_advance of the next (the few slots it serves are not in a search; a root request is therefore
- *                   answered by the evaluator launch AFTER the next one).
+ *                   (selfplay.py:83-104), the next ply's root -- expanded from the previous tree (reuse) or asked for as a request.
+ *                   In stream order (the default) a root request is answered by the very next evaluator launch.  With
+ *                   CCSP_ADVANCE_OVERLAPPED it may run on ANOTHER stream beside the next evaluator launch, provided it starts after the
+ *                   ccsp_advance of its round and ends before the ccsp_advance of the next (the few slots it serves are not in a search;
+ *                   a root request is then answered by the evaluator launch AFTER the next one).
+ *
+ * THE HAND-OFF (what replaces the reference's call `model.predict(to_model_input(leaf))`, MCTS.py:93, for a whole batch):
+ *   req    [n_slots] ccsp_request, device, CALLER-OWNED and zero-filled before the first call after ccsp_create / ccsp_reset /
+ *          ccsp_set_positions; the SAME buffer in every call of a context (a record also carries the slot's hand-off state between calls).
+ *          A slot with kind != 0 asks for the evaluation of `state` with `player` to move: the 32-byte position record is all the
+ *          evaluator needs (utils.to_model_input is a function of it: ccsp_net_forward_requests builds the 7 x 7 x 7 planes in its input
+ *          phase; ccsp_encode_requests writes them out for evaluators that want planes) -- 64 bytes per request where float32 planes
+ *          were 1372;
+ *   moves  [n_slots][CCSP_REQUEST_MOVES] uint16, device, caller-owned, the same buffer in every call: the legal moves of `state` in
+ *          Board.get_valid_moves' order (board.py:215-222), entry = action index (utils.encode_checker_index) | 0x8000 where the move wins;
+ *          req.k entries.  The move list is generated when the request is made, not when the answer arrives;
+ *   pk     [n_slots][CCSP_REQUEST_MOVES] float64, device: THE ANSWER, COMPACT -- pk[slot][j] = softmax(logits)[moves[slot][j] & 0x1FF], the
+ *          prior of the j-th legal move (the reference reads p[encode_checker_index(...)] per legal move, MCTS.py:97-109, and nothing
+ *          else of the 294 entries); v [n_slots] float32.  K x 8 bytes per answer where the full policy row was 2352.
+ *   Rows of slots that ask for nothing (kind == 0: game over, between plies, a selection given up at the deadline) are ignored.
+ *
  *   CCSP_ADVANCE_REUSE      selfplay.make_move returns the chosen child as a fresh root (selfplay.py:130-133) and the next ply evaluates the
  *                           positions of its subtree again; with this flag a position the previous ply's tree holds below the move that was
  *                           played is expanded from that tree's priors and value -- the evaluator is a function of the position alone, so
@@ -265,19 +282,42 @@ int ccsp_ply_end(ccsp_ctx *ctx, void *stream);
  *   CCSP_ADVANCE_LOG_GUARD  a slot whose finished ply might not find a free row in the sample log waits for the caller's next
  *                           ccsp_log_clear instead of ending its game in CCSP_ST_ERROR (for callers that harvest the log as they go).
  * model_sel (device, [n_slots], may be NULL): 1 where the request is to be answered by player two's model (selfplay.py:30,36,59).
- * Slots that ask for nothing in a round (game over, budget of evaluator-free simulations spent) ignore their row of the next answer.
- *   CCSP_ADVANCE_STAGGER    (ccsp_boundary) slot g starts its FIRST game hash(g) mod `sims` rounds late, so that the slots' plies end evenly
- *                           spread over the rounds from the start instead of in waves (every round then carries the same mix of cheap
- *                           and expensive tree work).  A game's record does not depend on when it is played.
+ *   CCSP_ADVANCE_STAGGER    (ccsp_boundary) a slot starts its FIRST game hash(id of that game) mod `span` ccsp_boundary CALLS late (span:
+ *                           ccsp_set_stagger_span, default `sims`; the countdown moves only in ccsp_boundary calls, so a caller that makes one
+ *                           every k-th round spreads the starts over k x span rounds), so that the slots' plies end evenly spread over the
+ *                           rounds from the start instead of in waves (every round then carries the same mix of cheap and expensive tree
+ *                           work).  A game's record does not depend on when it is played.
+ *   CCSP_ADVANCE_OVERLAPPED (ccsp_boundary) the call runs beside the next evaluator launch (see above).
  */
-enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2, CCSP_ADVANCE_STAGGER = 4, CCSP_ADVANCE_DEBUG = 8 /* diagnostic tallies in counters 12-14 */ };
+#define CCSP_REQUEST_MOVES 128
+typedef struct ccsp_request {
+    ccsp_state state;         /* the position to evaluate */
+    uint32_t kind;            /* 0 = nothing asked; 1 = a leaf, 3 / 4 = a ply's root */
+    uint32_t depth, link;     /* the engine's own: path length, where the new node hangs */
+    uint32_t player;          /* player to move in `state` (1 | 2) */
+    uint32_t k;               /* legal moves of `state`: entries of moves[slot] and of pk[slot] */
+    uint32_t walk[3];         /* the engine's own: a selection to be resumed */
+} ccsp_request;
+enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2, CCSP_ADVANCE_STAGGER = 4, CCSP_ADVANCE_DEBUG = 8 /* diagnostic tallies in counters 12-14 */,
+       CCSP_ADVANCE_OVERLAPPED = 16, CCSP_ADVANCE_ALL_FLAGS = 31 };
 int ccsp_enable_tree_reuse(ccsp_ctx *ctx);
 /* CCSP_ADVANCE_STAGGER: the number of ccsp_boundary calls over which the slots' first games begin (0 = the default, `sims`; at most 65535).
  * A span of a whole game's worth of calls puts a restarting run into its steady state -- games ending at an even rate -- as soon as the last
  * slot has started.  Call it before the first ccsp_boundary. */
 int ccsp_set_stagger_span(ccsp_ctx *ctx, int boundary_calls);
-int ccsp_advance(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
-int ccsp_boundary(ccsp_ctx *ctx, const double *p, const float *v, float *planes, uint8_t *model_sel, int flags, void *stream);
+int ccsp_advance(ccsp_ctx *ctx, const double *pk, const float *v, ccsp_request *req, uint16_t *moves, uint8_t *model_sel, int flags, void *stream);
+int ccsp_boundary(ccsp_ctx *ctx, const double *pk, const float *v, ccsp_request *req, uint16_t *moves, uint8_t *model_sel, int flags, void *stream);
+/* C1 for a batch of requests (utils.to_model_input, utils.py:101-160): planes [n][7][7][7] float32, all zero for rows that ask for nothing --
+ * the input of evaluators that take planes (a PyTorch module, a reference-style model.predict). */
+int ccsp_encode_requests(const ccsp_request *req, int n, float *planes, void *stream);
+/* the compact answer from a FULL policy: pk[i][j] = p[i][moves[i][j] & 0x1FF] for j < req[i].k (p [n][294] float64 = Model.predict's first
+ * result, model.py:21-24), for the same evaluators */
+int ccsp_gather_priors(const ccsp_request *req, const uint16_t *moves, const double *p, int n, double *pk, void *stream);
+/* test hook: the built-in table evaluators (CCSP_EVAL_UNIFORM / HASH / FORWARD) as an external evaluator of requests -> (pk, v) */
+int ccsp_debug_table_eval(int evaluator, const ccsp_request *req, const uint16_t *moves, int n, double *pk, float *v, void *stream);
+/* The three limits of ccsp_advance below, per context (a value < 1 / < 0 / < 0 leaves that one as it is).  A context starts with the
+ * process-wide defaults, which the ccsp_debug_advance_* hooks change for contexts created AFTERWARDS. */
+int ccsp_set_advance_limits(ccsp_ctx *ctx, int budget, int time_cap_ticks, int deadline_ticks);
 /* evaluator-free simulations (won leaves, reused positions) a slot takes up in ONE ccsp_advance before the selection that ends the call
  * (default 8; if that selection too ends on such a leaf the simulation is completed and the call ends without a request: bounds the launch's
  * length; results do not depend on it; at least 1: a slot must be able to get past a won leaf).  Returns the previous value; n < 1 only reads it. */
@@ -311,6 +351,12 @@ int ccsp_net_pack(const float *plain, float *packed);
  * packed = device copy of ccsp_net_pack's output. */
 int ccsp_net_forward(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream);
 
+/* The same network on a batch of REQUESTS of the free-running path (ccsp_advance / ccsp_boundary above): the input phase builds the planes
+ * of req[i].state itself (C1 inside the evaluator: 64 bytes read per position instead of 1372), the epilogue writes the float64 softmax of
+ * the k legal moves only (pk [n][CCSP_REQUEST_MOVES]) and v [n].  Bit-identical to ccsp_net_forward on ccsp_encode_requests' planes followed
+ * by ccsp_gather_priors.  Rows with kind == 0 are evaluated on an all-zero input and not written. */
+int ccsp_net_forward_requests(const float *packed, const ccsp_request *req, const uint16_t *moves, int n, double *pk, float *v, void *stream);
+
 /* test / measurement hook: workgroup shape of ccsp_net_forward -- 8, 4 or 2 positions per workgroup; any other value restores the
  * default: by batch size (batches that cannot fill the GPU run in the shape whose single workgroup is done sooner: 2 up to 512
  * positions, 4 up to 1024, 8 beyond).  Bit-identical results in every shape.  Returns the value in force (0 = by batch size). */
@@ -327,7 +373,9 @@ int ccsp_log_clear(ccsp_ctx *ctx, void *stream);
 int ccsp_log_device_ptrs(ccsp_ctx *ctx, ccsp_state **state, ccsp_sample_meta **meta, double **pi);   /* device pointers */
 int ccsp_read_log(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_state *state, ccsp_sample_meta *meta, double *pi);
 int ccsp_read_results(ccsp_ctx *ctx, uint64_t first, uint64_t n, ccsp_game_result *out);
-/* root edges of a slot's tree: Edge.stats N, W, P (MCTS.py:31-36) and the action index of each edge */
+/* root edges of the tree of the search a slot FINISHED last: Edge.stats N, W, P (MCTS.py:31-36) and the action index of each edge.  Fused and
+ * lock-step paths: valid until the next ply's root is expanded.  Free-running path: with CCSP_ADVANCE_REUSE the finished tree stays whole
+ * while the next ply is searched; without, until the answer to the next root request has been taken. */
 int ccsp_read_root(ccsp_ctx *ctx, int slot, int *k, uint32_t *N, double *W, double *P, uint16_t *mv);
 /* test hook: digest of the whole tree in the reference's edge order (see gen_golden.py tree_digest) */
 int ccsp_debug_tree_digest(ccsp_ctx *ctx, int slot, uint64_t *digest, uint64_t *nodes, uint64_t *edges);

@@ -685,6 +685,8 @@ typedef struct {
     int n_plies;                      /* all plies incl. the random opening */
     int n_hist;                       /* records returned in play_history */
     long evals, terminals;
+    int n_searched;                   /* plies searched in all = rows the hist_* buffers hold when the game was NOT won (a discarded game
+                                         returns (None, None), selfplay.py:45-47, 72-74, but its searches happened: tests compare them too) */
 } orc_game_out;
 
 /* buffers: ply_moves[max_plies][3] (kind 0 random / 1 tau=1 / 2 tau=0.01, id, dest);
@@ -764,6 +766,7 @@ int orc_selfplay(uint64_t seed, uint64_t game, int sims, int evaluator, int rand
         }
         out->n_hist = n_hist - drop;
     } else out->n_hist = 0;
+    out->n_searched = n_hist;
     return out->status;
 }
 

@@ -23,7 +23,7 @@ class SearchOut(C.Structure):
 
 class GameOut(C.Structure):
     _fields_ = [('status', C.c_int), ('reward', C.c_int), ('n_plies', C.c_int), ('n_hist', C.c_int),
-                ('evals', C.c_long), ('terminals', C.c_long)]
+                ('evals', C.c_long), ('terminals', C.c_long), ('n_searched', C.c_int)]
 
 
 EVAL_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_double),
@@ -194,9 +194,11 @@ def selfplay(seed, game, sims, evaluator, randomised=False, fn=None, max_plies=1
     lib().orc_selfplay(seed, game, sims, evaluator, int(randomised), int(evaluator2), cb, None, max_plies, u8(ply_moves), u8(hp), u8(hl),
                        u8(hpl), pi.ctypes.data_as(C.POINTER(C.c_double)), C.byref(out))
     n, h = out.n_plies, out.n_hist
+    won = out.status in (ST_WON_P1, ST_WON_P2)
+    a = h if won else out.n_searched                     # a discarded game hands nothing back, but its searched plies are in the buffers
     return dict(status=out.status, reward=out.reward, plies=ply_moves[:n].copy(), hist_pos12=hp[:h].copy(),
                 hist_last=hl[:h].copy(), hist_player=hpl[:h].copy(), pi=pi[:h].copy(), evals=out.evals,
-                terminals=out.terminals)
+                terminals=out.terminals, n_searched=out.n_searched, searched_pos12=hp[:a].copy(), searched_pi=pi[:a].copy())
 
 
 EV_GREEDY = 100          # a GreedyPlayer seat in arena_game (next-4)

@@ -194,9 +194,10 @@ def test_search_with_net_priors_matches_oracle(golden_dir):
 
 
 def test_config3_full_size_ply_matches_oracle(golden_dir):
-    """BASELINE.json config 3 at FULL size, exactly as bench.py runs it: 4096 slots x 400 simulations with good_model.h5,
-    PipelinedSelfPlay (two half-batches on two HIP streams, 25 simulation steps per captured hipGraph, fused evaluator
-    kernel on 2048 positions per launch).  One searched ply; 16 rows of the sample log spread over both halves are
+    """BASELINE.json config 3 at FULL size on the LOCK-STEP kernels (what the arena, small batches and bench.py's `3_lock_step` variant
+    run; the delivered free-running mode at this size is test_full_size_restarting_run_plays_the_oracles_games): 4096 slots x 400
+    simulations with good_model.h5, PipelinedSelfPlay (two half-batches on two HIP streams, 25 simulation steps per captured hipGraph,
+    fused evaluator kernel on 2048 positions per launch).  One searched ply; 16 rows of the sample log spread over both halves are
     re-searched by the CPU oracle calling back into the same evaluator one position at a time: pi must agree bit for
     bit (400 simulations of float64 PUCT on float32-net priors, and the evaluator's independence of its batch)."""
     import torch
@@ -512,33 +513,46 @@ def test_config1_one_whole_game_50_sims_matches_oracle(golden_dir):
 
 def test_full_size_restarting_run_plays_the_oracles_games(golden_dir):
     """BASELINE config 3 at FULL size in the delivered mode: 4096 restarting slots x 400 simulations with good_model.h5 through
-    SelfPlayRun exactly as bench.py runs it (two half-batches, hipGraphs, harvests every 4 plies, worker thread), until the first
-    games have ended; the TWO shortest won games are then replayed by the CPU oracle with a callback into the same evaluator, one
-    position per call: every searched position, every pi and z must agree bit for bit.  (What a whole game needs to come out right
-    at this size: 400-simulation searches on float32-net priors, the evaluator's independence of its batch slot, the end-of-ply
-    rules, the restart of a slot, the harvest and the host-side regrouping of rows by game.)"""
+    SelfPlayRun exactly as bench.py runs it (two half-batches of free-running slots on two streams, tree reuse, requests evaluated in
+    place by the fused kernel, 25 rounds per hipGraph, harvests every 4 plies, worker thread) -- and the test says so: it fails if the
+    run fell back to lock-step, ran without reuse, off the HIP evaluator or off its captured graphs.  When enough games have ended,
+    TEN of them are replayed by the CPU oracle with a callback into the same evaluator, one position per call: eight won games spread
+    over the length distribution (shortest to longest: long games carry the most reused subtrees) -- every searched position, every pi
+    and z, bit for bit -- and one game discarded by each rule that occurred (status, ply count, evaluator calls: a discarded game's
+    rows are not kept, selfplay.py:45-47, 72-74)."""
     import torch
     from chinesecheckersagent_amd import _lib, selfplay as sp
     from chinesecheckersagent_amd.model import ResidualCNN
     m = ResidualCNN()
     m.load_weights(golden_dir + '/good_model.h5')
+    assert m.backend == 'hip'
     seed, sims, G = 20261003, 400, 4096
     run = sp.SelfPlayRun(m, n_games=G * 4, sims=sims, seed=seed, max_slots=G)
     try:
-        won = []
-        for _ in range(12):                                   # <= 96 plies: the first games end after ~35 searched plies
+        assert run.free_running and hasattr(run.b, 'parts') and len(run.b.parts) == 2       # the path bench.py times, not a fallback
+        assert all(b.free_running and b.reuse and b.log_guard and b.use_graph for b in run.b.parts)
+        won = disc = []
+        for _ in range(20):                                   # <= 160 steps of 401 rounds (a slot plays ~1.3 plies per step)
             for _ in range(8):                                # (play_ply harvests every sp.HARVEST_EVERY plies by itself)
                 run.play_ply()
             st = run.store.results['status']
             won = np.nonzero((st == _lib.ST_WON_P1) | (st == _lib.ST_WON_P2))[0]
-            if len(won) >= 8:
+            disc = np.nonzero((st == _lib.ST_DISCARD_REPETITION) | (st == _lib.ST_DISCARD_NO_PROGRESS))[0]
+            if len(won) >= 64 and len(disc) >= 1:
                 break
-        assert len(won) >= 2 and run.counters()['errors'] == 0
-        parts = run.b.parts if hasattr(run.b, 'parts') else [run.b]
-        assert all(b._graph is not None for b in parts)       # the captured-graph path really ran
+        c = run.counters()
+        assert len(won) >= 8 and len(disc) >= 1 and c['errors'] == 0
+        assert c['cache_hits'] > 0.15 * c['expansions'], (c['cache_hits'], c['expansions'])       # tree reuse really answered expansions
+        assert all(b._graph is not None and b._unroll == sp.BatchSelfPlay.FREE_UNROLL for b in run.b.parts)     # the captured-graph path really ran
         run.store.take_finished()
         st_, meta_, pi_ = (np.concatenate([r[i] for r in run.store._records]) for i in range(3))
-        shortest = sorted(won, key=lambda j: int(run.store.results['n_plies'][j]))[:2]
+        results = run.store.results.copy()
+        by_len = sorted(won, key=lambda j: int(results['n_plies'][j]))
+        picked = [by_len[i] for i in sorted(set(np.linspace(0, len(by_len) - 1, 8).astype(int)))]
+        for kind in (_lib.ST_DISCARD_REPETITION, _lib.ST_DISCARD_NO_PROGRESS):
+            of_kind = [j for j in disc if int(results['status'][j]) == kind]
+            if of_kind:
+                picked.append(min(of_kind, key=lambda j: int(results['n_plies'][j])))
     finally:
         run.close()
 
@@ -548,10 +562,15 @@ def test_full_size_restarting_run_plays_the_oracles_games(golden_dir):
         np.ctypeslib.as_array(p_out, shape=(294,))[:] = p[0].cpu().numpy()
         v_out[0] = float(v[0])
     fn = orc.EVAL_FN(cb)
-    for j in shortest:
+    assert len(picked) >= 9
+    for j in picked:
         o = orc.selfplay(seed, int(j), sims, 4, fn=fn)
-        res = run.store.results[j]
-        assert o['status'] == int(res['status']) and o['reward'] == int(res['reward']) and len(o['plies']) == int(res['n_plies'])
+        res = results[j]
+        assert o['status'] == int(res['status']) and len(o['plies']) == int(res['n_plies']) and o['evals'] == int(res['expansions']), j
+        if o['status'] not in (orc.ST_WON_P1, orc.ST_WON_P2):
+            assert o['n_searched'] == int(res['n_samples'])
+            continue
+        assert o['reward'] == int(res['reward'])
         rows = np.nonzero(meta_['game'] == j)[0]
         rows = rows[np.argsort(meta_['ply'][rows])]
         assert len(rows) == len(o['pi']) == int(res['n_samples'])
@@ -628,9 +647,14 @@ def test_bench_launcher_world2_on_one_device(tmp_path):
         assert doc['steps'] == 3 and doc['errors'] == 0 and doc['backend'] == 'hip' and doc['value'] > 0 and doc['degraded'] is False
         # what the driver's record keeps: BASELINE's games/s and the run's description inside `config`, the isolated figure beside the
         # delivered one in `roofline`, host CPU seconds and peak RSS of every rank
-        ms = doc['config']['measured']
-        assert ms['games_per_s'] >= 0 and 0 <= ms['discard_rate'] <= 1 and ms['timed_region_s_total'] > 0 and ms['node_expansions_per_s'] == doc['value']
-        assert len(ms['host_cpu_s_per_rank']) == len(ms['host_peak_rss_mb_per_rank']) == doc['n_gpus'] and min(ms['host_peak_rss_mb_per_rank']) > 100
+        cfg, ms = doc['config'], doc['measured']
+        # what the driver's record keeps of `config`: scalars only, strings of at most 120 characters -- BASELINE's games/s among them
+        assert all(isinstance(x, (int, float, bool)) or (isinstance(x, str) and len(x) <= 120) for x in cfg.values()), cfg
+        assert cfg['workload'].startswith('config 3') and cfg['games_per_s'] >= 0 and 0 <= cfg['discard_rate'] <= 1 and cfg['timed_region_s'] > 0
+        assert cfg['node_expansions_per_s'] == doc['value'] and cfg['net_evals_per_s'] > 0 and 0 <= cfg['tree_reuse_hit_rate'] < 1
+        assert 0 <= cfg['idle_row_share'] < 1 and cfg['host_cores_per_rank'] > 0 and cfg['host_peak_rss_mb_per_rank'] > 100
+        assert len(ms['host_cpu_s_per_rank']) == len(ms['host_peak_rss_mb_per_rank']) == doc['n_gpus']
+        assert doc['roofline']['frac_by_step'] > 0 and doc['roofline']['step_ms_per_launch'] > 0
         # (32 positions per launch: 45-us launches whose medians wander by several per cent from burst to burst)
         assert 0 < doc['roofline']['frac'] <= doc['roofline']['frac_isolated'] * 1.25 and doc['roofline']['avg_launch_ms_isolated'] > 0
         assert doc['roofline']['bound'] == 'mfma' and 0 < doc['roofline']['frac'] < 1
@@ -643,6 +667,7 @@ def test_bench_launcher_world2_on_one_device(tmp_path):
     assert cb['config1_reference_shaped_python_numpy_net']['value'] > 0
     c5 = two['config5']
     assert 'failed' not in c5 and c5['selfplay_games'] == 4 and c5['train_s'] > 0 and 'arena_wins' in c5
+    assert c5['train_warm_up_s'] > 0 and c5['train_epochs_s'] >= 0 and c5['train_first_steps_s'] >= 0
     assert len(two['per_rank_expansions']) == 2
     assert sum(two['per_rank_expansions']) == one['per_rank_expansions'][0]           # id-sharding: same games, same work
     a, b = two['variants']['2a_fused_table_evaluator'], one['variants']['2a_fused_table_evaluator']

@@ -356,10 +356,26 @@ def test_c_abi_error_paths(eng):
     assert L.ccsp_expand_backup(e.ctx, p.data_ptr(), v.data_ptr(), None) == ESTATE
     assert L.ccsp_expand_backup_select(e.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(), None) == ESTATE
     assert L.ccsp_expand_backup_select(e.ctx, p.data_ptr(), v.data_ptr(), None, None) == _lib.EINVAL
-    # the free-running entry points: unknown flag bits, tree reuse before its pool exists, a stagger span beyond the slot's 16-bit countdown
-    assert L.ccsp_advance(e.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(), None, 1 << 9, None) == _lib.EINVAL
-    assert L.ccsp_advance(e.ctx, p.data_ptr(), v.data_ptr(), planes.data_ptr(), None, _lib.ADVANCE_REUSE, None) == ESTATE
-    assert L.ccsp_boundary(e.ctx, p.data_ptr(), v.data_ptr(), None, None, 0, None) == _lib.EINVAL
+    # the free-running entry points: unknown flag bits, tree reuse before its pool exists, missing hand-off buffers, a stagger span
+    # beyond the slot's 16-bit countdown
+    req, moves, pk, v4 = e.request_buffers()
+    assert L.ccsp_advance(e.ctx, pk.data_ptr(), v4.data_ptr(), req.data_ptr(), moves.data_ptr(), None, 1 << 9, None) == _lib.EINVAL
+    assert L.ccsp_advance(e.ctx, pk.data_ptr(), v4.data_ptr(), req.data_ptr(), moves.data_ptr(), None, _lib.ADVANCE_REUSE, None) == ESTATE
+    assert L.ccsp_boundary(e.ctx, pk.data_ptr(), v4.data_ptr(), None, moves.data_ptr(), None, 0, None) == _lib.EINVAL
+    assert L.ccsp_boundary(e.ctx, pk.data_ptr(), v4.data_ptr(), req.data_ptr(), None, None, 0, None) == _lib.EINVAL
+    assert L.ccsp_set_advance_limits(None, 1, 1, 1) == _lib.EINVAL and L.ccsp_set_advance_limits(e.ctx, 4, 0, 0) == 0
+    assert L.ccsp_encode_requests(None, 4, planes.data_ptr(), None) == _lib.EINVAL and L.ccsp_encode_requests(None, 0, None, None) == 0
+    assert L.ccsp_gather_priors(req.data_ptr(), moves.data_ptr(), None, 4, pk.data_ptr(), None) == _lib.EINVAL
+    assert L.ccsp_net_forward_requests(None, req.data_ptr(), moves.data_ptr(), 4, pk.data_ptr(), v4.data_ptr(), None) == _lib.EINVAL
+    assert L.ccsp_debug_table_eval(7, req.data_ptr(), moves.data_ptr(), 4, pk.data_ptr(), v4.data_ptr(), None) == _lib.EINVAL
+    # a request buffer that holds STALE records (a caller that did not zero it after ccsp_reset): a record's kind means nothing to a
+    # slot that has not asked -- the games start as they should
+    stale = np.zeros(4, dtype=_lib.REQUEST_DTYPE); stale['kind'] = 3; stale['k'] = 126
+    req.copy_(torch.from_numpy(stale.view(np.uint8).reshape(4, 64)))
+    e.reset()
+    e.boundary(pk, v4, req, moves)
+    torch.cuda.synchronize()
+    assert e.counters()['errors'] == 0 and e.counters()['expansions'] == 0 and (e.slots()['status'] == _lib.ST_RUNNING).all()
     assert L.ccsp_set_stagger_span(e.ctx, 65536) == _lib.EINVAL and L.ccsp_set_stagger_span(e.ctx, -1) == _lib.EINVAL
     assert L.ccsp_set_stagger_span(e.ctx, 4010) == 0 and L.ccsp_set_stagger_span(None, 1) == _lib.EINVAL
     assert L.ccsp_debug_read_slots(e.ctx, None) == _lib.EINVAL

@@ -309,3 +309,44 @@ def test_run_ranks_times_out_and_kills_a_rank_that_ignores_sigterm():
     t0 = time.time()
     assert launch.run_ranks(stubborn, 2, extra_env={'FAIL_ONE': '1'}, kill_grace=1.0, poll=0.05) == 7
     assert time.time() - t0 < 20
+
+
+def test_the_hot_path_entry_is_guarded(monkeypatch, capsys):
+    """SelfPlayRun's entry check (no GPU needed): a CUDA model that is not on the fused HIP kernel, a reference-style .predict object at a
+    batch size where it matters, or lock-step forced at >= 1024 slots leaves the delivered path -- reported once on stderr, an error
+    under CCSP_STRICT=1; the delivered configuration, small plumbing runs and deliberate comparisons pass silently"""
+    from chinesecheckersagent_amd import _lib, selfplay as sp
+
+    class Dev(object):
+        def __init__(self, t):
+            self.type = t
+
+    class Fake(object):
+        def __init__(self, backend, dev='cuda', precision='fp32'):
+            self.backend, self.device, self.precision = backend, Dev(dev), precision
+
+        def evaluate_batch(self, x):
+            raise AssertionError
+
+    class Duck(object):
+        def predict(self, x):
+            raise AssertionError
+    monkeypatch.delenv('CCSP_STRICT', raising=False)
+    sp._warned.clear()
+    sp._check_hot_path(Fake('hip'), None, 4096, None)                  # the delivered evaluator, any size
+    sp._check_hot_path(Fake('torch', dev='cpu'), None, 4096, None)     # a CPU module: not this check's business (the engine refuses it)
+    sp._check_hot_path(Duck(), None, 8, None)                          # plumbing sizes with a .predict object
+    sp._check_hot_path(Fake('hip'), Fake('hip'), 1024, True)
+    assert capsys.readouterr().err == ''
+    for args, word in (((Fake('torch'), None, 64, None), 'PyTorch modules'), ((Fake('torch', precision='fp64'), None, 64, None), 'fp64'),
+                       ((Fake('hip'), Fake('torch'), 64, None), 'model2'), ((Duck(), None, 2048, None), 'one position at a time'),
+                       ((Fake('hip'), None, 1024, False), 'lock-step')):
+        sp._warned.clear()
+        sp._check_hot_path(*args)
+        sp._check_hot_path(*args)                                       # ... once
+        err = capsys.readouterr().err
+        assert err.count('leaves the delivered hot path') == 1 and word in err, (word, err)
+        monkeypatch.setenv('CCSP_STRICT', '1')
+        with pytest.raises(_lib.CcspError, match='hot path'):
+            sp._check_hot_path(*args)
+        monkeypatch.delenv('CCSP_STRICT')
