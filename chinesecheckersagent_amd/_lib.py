@@ -136,14 +136,21 @@ def prefer_blocking_sync(device=None):
     """hipSetDeviceFlags(hipDeviceScheduleBlockingSync): a host thread that waits for the GPU (the harvest's synchronisation, a rank of
     the N-GPU generator between two graph launches) SLEEPS instead of spinning.  Measured on the GPU box (tools/host_spin_probe.py): a
     rank of the generator keeps 2.0 host cores busy by default -- one of them this spin -- and 1.0 with the flag, at the same
-    throughput; eight ranks on a 16-core quota leave the converter threads no core otherwise.  Best called before the process
-    touches the GPU (launch.init_rank and bench.py do); later calls may be refused by the runtime, which is harmless.
+    throughput; eight ranks on a 16-core quota leave the converter threads no core otherwise.  Only BEFORE the process touches the
+    GPU (launch.init_rank and bench.py do): on a process whose GPU is already initialised this is a no-op (see below).
     CCSP_NO_BLOCKING_SYNC=1 leaves the runtime's default.  -> the runtime's return code, or None if not attempted."""
     key = -1 if device is None else int(device)          # the flags are per DEVICE: a run on device N sets them there, once
     if key in _blocking_sync or os.environ.get('CCSP_NO_BLOCKING_SYNC') == '1':
         return _blocking_sync.get(key)
     try:
         import torch
+        if torch.cuda.is_initialized():
+            # NEVER on a process that already uses the GPU.  Measured in round 5 (tools/diag_hang.py, gpurun_out/r5g4_diag.log): changing
+            # the scheduling flags of an ACTIVE device leaves the runtime waiting for ever inside the next hipFree (torch's
+            # empty_cache() in front of a graph capture) -- the rank entry points (launch.init_rank, bench.py) set the flag before
+            # their first GPU call; a process that comes here later keeps the runtime's default (a spinning wait: one more host core)
+            _blocking_sync[key] = None
+            return None
         hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))   # the runtime torch has loaded: the process's only one
         prev = C.c_int(-1)
         if device is not None:

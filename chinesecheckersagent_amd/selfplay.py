@@ -654,7 +654,7 @@ class SelfPlayRun(object):
         import os
         if os.environ.get('CCSP_MALLOPT') == '1':
             tune_host_allocator()
-        _lib.prefer_blocking_sync(device)                  # (this run's device; effective when the process has not touched it yet)
+        _lib.prefer_blocking_sync(device)                  # (this run's device; a no-op once the process has initialised the GPU)
         n_games = int(n_games)
         if not off_path_ok:                                # (off_path_ok: a deliberate comparison, e.g. bench.py's lock-step variant)
             _check_hot_path(model1, model2, min(n_games, int(max_slots)), free_running)

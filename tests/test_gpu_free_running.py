@@ -244,7 +244,9 @@ def test_restarting_free_running_slots_play_the_oracles_games(ev):
         for j, r in enumerate(rows.get(game, [])):
             assert [int(x) for x in st[r]['pos'].reshape(12)] == [int(x) for x in want_pos[j]], (tag, j)
             assert np.array_equal(pi[r], want_pi[j]), 'pi of searched ply %d of %s differs from the oracle' % (j, tag)
-    assert {orc.ST_WON_P1, orc.ST_WON_P2} & kinds and (orc.ST_DISCARD_NO_PROGRESS in kinds or orc.ST_DISCARD_REPETITION in kinds)
+    # (games END in wins under the forward evaluator; under the hash evaluator -- random priors and values -- nearly all are discarded)
+    assert orc.ST_DISCARD_NO_PROGRESS in kinds or orc.ST_DISCARD_REPETITION in kinds
+    assert ev != 2 or {orc.ST_WON_P1, orc.ST_WON_P2} & kinds
 
 
 def test_requests_evaluated_in_place_equal_planes_evaluated(golden_dir):

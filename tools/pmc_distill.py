@@ -42,7 +42,9 @@ for k, x in list(d.items()):
                     workload='4096 games x 400 simulations, config 2a; launches of FOUR plies, every figure here divided by four = per ply',
                     source=src)
     elif k.startswith('net_forward_kernel') and 'Cfg<8, 8>' in k:
-        c['net_forward_kernel'] = dict(n=x['grid_threads'] // 64, fetch_size_kb=x['FETCH_SIZE'], write_size_kb=x['WRITE_SIZE'],
+        # round 5: two forms of the kernel -- <..., true> evaluates the free-running path's REQUEST records (what the headline runs:
+        # kept under 'net_forward_kernel'), <..., false> float32 planes (the lock-step path: 'net_forward_kernel_planes')
+        c['net_forward_kernel' if ', true>' in k else 'net_forward_kernel_planes'] = dict(n=x['grid_threads'] // 64, fetch_size_kb=x['FETCH_SIZE'], write_size_kb=x['WRITE_SIZE'],
                                        mfma_insts=x['SQ_INSTS_VALU_MFMA_F32'], mfma_busy_cycles=x['SQ_VALU_MFMA_BUSY_CYCLES'],
                                        grbm_gui_active=x['GRBM_GUI_ACTIVE'],
                                        mfma_busy_frac=x['SQ_VALU_MFMA_BUSY_CYCLES'] / (x['GRBM_GUI_ACTIVE'] * 128.0),   # 1024 SIMDs / 8 XCD clocks
