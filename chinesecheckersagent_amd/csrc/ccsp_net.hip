@@ -103,7 +103,7 @@ static_assert(PLAIN_TOTAL == 244920, "249852 parameters minus the 4 x 1233 Batch
 // is followed by one zero cell (the right neighbour of column 4 AND the left neighbour of the next row's column 0), every map by
 // one zero row of six (the bottom halo of this map AND the top halo of the next).  Neighbour (dr, dc) = + 6 dr + dc.
 constexpr int PAD0 = 7, PADPOS = 36;
-// A workgroup of NW waves carries NB positions (rows = position * 25 + cell, MT tiles of 16 rows).  Two shapes are built:
+// A workgroup of NW waves carries NB positions (rows = position * 25 + cell, MT tiles of 16 rows).  Four shapes are built:
 //   <8, 8>: 200 rows = 13 tiles (4 % padding), one 137-KB workgroup per CU, two waves per SIMD from the SAME workgroup --
 //           at every barrier both are out of matrix work at once;
 //   <4, 4>: 100 rows = 7 tiles (12 % padding), 72 KB, four waves: a workgroup is done in 0.6 of the time -- the shape of batches that
@@ -114,12 +114,20 @@ constexpr int PAD0 = 7, PADPOS = 36;
 // compute tile 6); 32-column layers -- wave & 1 = column tile, F32 row tiles from F32 * (wave >> 1) plus, where the tiles do not
 // divide (XT), a 1/NSPLIT share of the k-range of the last tile MT - 1.  Every shape forms every output by the same chains in the
 // same order: a position's result does not depend on the shape.
+//   <1, 8>: 25 rows = 2 tiles, 26 KB, eight waves on ONE position (round 5): every tile job of the 3x3 layers is shared by TWO waves
+//           (half the k-range = two of the four segments each), the 1x1 layers have a job for every wave or every second one -- half the
+//           matrix work per CU of <2, 8>: the shape of the batches whose whole launch is ONE workgroup per CU and nothing but latency
+//           (one game of selfplay(), the arena's and config 5's few dozen slots per GPU: up to 256 positions).
 template <int NBv, int NWv>
 struct Cfg {
     static constexpr int NB = NBv, NW = NWv, NTH = NWv * 64, ROWS = NBv * 25, MT = (NBv * 25 + 15) / 16;
     static constexpr int NSPLIT = NWv / 2;                       // row groups of the 32-column layers = waves sharing the k-range of tile MT - 1
-    static constexpr int F32 = MT / NSPLIT;                      // full row tiles per wave in the 32-column layers (3, 3, 1)
-    static constexpr int XT = MT - F32 * NSPLIT;                 // 1: a last row tile shared by the NSPLIT waves of a column tile; 0: none
+    static constexpr bool ALLSPLIT = MT < NSPLIT;                // fewer row tiles than row groups (<1, 8>): EVERY tile of the 3x3 layers is k-split
+    static constexpr int NSH = ALLSPLIT ? NSPLIT / MT : NSPLIT;  // waves sharing the k-range of a split tile
+    static constexpr int XTILES = ALLSPLIT ? MT : 1;             // row tiles whose 3x3 outputs reach the next layer as partial sums (Smem::part)
+    static constexpr int F32 = MT / NSPLIT;                      // full row tiles per wave in the 32-column layers (3, 3, 1; 0 when ALLSPLIT)
+    static constexpr int F32A = F32 > 0 ? F32 : 1;               // (array extents: at least one slot)
+    static constexpr int XT = ALLSPLIT ? 0 : MT - F32 * NSPLIT;  // 1: a last row tile shared by the NSPLIT waves of a column tile; 0: none
     static constexpr int NH = NWv / 4;                           // row halves of the 64-column layers
     static constexpr int F64 = (MT + NH - 1) / NH;               // row tiles per wave in the 64-column layers (7, 7, 2)
     static constexpr int M64 = MT - F64;                         // first tile of the second half (6: tile 6 twice; 0; 2)
@@ -128,10 +136,18 @@ struct Cfg {
     static constexpr int HB = NBv < 4 ? 4 : NBv;                 // positions the heads are laid out for (the 4 x 4 MFMA carries four at a time)
     static constexpr int NSEG = CCSP_NET_SEG_L2;                 // k-segments every output of a 3x3 layer is summed from (gemm_tiles_split): the
                                                                  // SAME in every shape, so that both shapes compute a position with the same bits
-    static constexpr int PADROWS = PAD0 + NBv * PADPOS + 1;
+    static constexpr int PADROWS_ = PAD0 + NBv * PADPOS + 1, PADROWS_HEADS = (HB * 400 + LDY - 1) / LDY;
+    static constexpr int PADROWS = PADROWS_ > PADROWS_HEADS ? PADROWS_ : PADROWS_HEADS;   // (the policy conv output of HB positions aliases y1)
     static constexpr int INROWS = NBv * 49 + 56;                 // staged input planes + what padding rows / the zero-weight 10th tap reach
     static constexpr int NTW = (19 + NWv - 1) / NWv;             // policy dense: column tiles per wave
-    static_assert((XT == 0 || XT == 1) && F32 >= 1 && F32 <= 3 && F64 <= 7 && MT <= 13 && (NWv == 4 || NWv == 8), "tile shares");
+#ifndef CCSP_NET_PDG_SMALL
+#define CCSP_NET_PDG_SMALL 1
+#endif
+    // policy dense: groups of four k the weight loads run ahead.  A batch that fills the GPU streams the layer's 470 KB per workgroup at
+    // what L2 delivers (one group ahead is enough; more was slower); the small shapes' few workgroups wait for L2 LATENCY instead.
+    static constexpr int PDG = NBv <= 2 ? CCSP_NET_PDG_SMALL : CCSP_NET_PDG;
+    static_assert((XT == 0 || XT == 1) && (F32 >= 1 || ALLSPLIT) && F32 <= 3 && F64 <= 7 && MT <= 13 && (NWv == 4 || NWv == 8), "tile shares");
+    static_assert(!ALLSPLIT || (NSPLIT % MT == 0 && NSEG % NSH == 0 && F64 == 1 && M64 + 1 == MT), "<1, 8>: two waves per 3x3 tile job, one 64-column job per wave");
 };
 
 template <typename C>
@@ -139,15 +155,18 @@ struct Smem {
     float x[C::MT * 16 * LDX > 4 * C::HB * 320 ? C::MT * 16 * LDX : 4 * C::HB * 320];   // 64-channel trunk activations; the policy dense
                                          // layer's partial sums [4][HB][320] alias it
     float y1[C::PADROWS * LDY];          // 32-channel 1x1 output = 3x3 input, zero halo; the policy conv output aliases it
-    float y2[C::MT * 16 * LDY];          // 32-channel 3x3 output; the stem's input planes and the logits / value scratch alias it
-    float part[2][C::NSEG][256];         // partial sums (one per k-segment) of the k-split last row tile of the 3x3 layers
-    static_assert(C::INROWS * LDI <= C::MT * 16 * LDY, "the staged input planes alias y2");
+    static constexpr int Y2A = C::MT * 16 * LDY, Y2B = C::INROWS * LDI, Y2C = 256 + C::HB * (NPOL_PAD + 32);
+    static constexpr int Y2N = Y2A > Y2B ? (Y2A > Y2C ? Y2A : Y2C) : (Y2B > Y2C ? Y2B : Y2C);
+    float y2[Y2N];                       // 32-channel 3x3 output; the stem's input planes and the logits / value scratch alias it
+    float part[2 * C::XTILES][C::NSEG][256];   // partial sums (one per k-segment) of the k-split row tiles of the 3x3 layers: [tile * 2 + column tile]
+    static_assert(C::INROWS * LDI <= Y2N, "the staged input planes alias y2");
     static_assert(C::MT * 16 * 16 <= C::PADROWS * LDY && C::HB * 400 <= C::PADROWS * LDY, "the policy conv output aliases y1");
-    static_assert(256 + C::HB * (NPOL_PAD + 32) <= C::MT * 16 * LDY, "logits and value scratch alias y2");
+    static_assert(256 + C::HB * (NPOL_PAD + 32) <= Y2N, "logits and value scratch alias y2");
 };
 static_assert(sizeof(Smem<Cfg<8, 8>>) + 3 * 6900 <= 160 * 1024, "<8,8>: one evaluator workgroup per CU plus three tree-kernel workgroups");
 static_assert(2 * sizeof(Smem<Cfg<4, 4>>) + 7800 <= 160 * 1024, "<4,4>: two evaluator workgroups per CU plus a tree-kernel workgroup");
 static_assert(sizeof(Smem<Cfg<2, 8>>) <= 64 * 1024, "<2,8>: a small workgroup");
+static_assert(sizeof(Smem<Cfg<1, 8>>) <= 64 * 1024, "<1,8>: a small workgroup");
 
 // the packed weights as a buffer resource: loads take a scalar byte offset (+ the lane's 16 bytes), no vector address math
 struct WBuf {
@@ -301,6 +320,47 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
     }
 }
 
+// <1, 8> (Cfg::ALLSPLIT): a wave's whole share of a 3x3 layer is a 1/NSH part of ONE tile's k-range -- whole segments of the same NSEG
+// chains as everywhere else (kpart * SPW .. + SPW - 1; the segments of every part are equally long: asserted), their raw sums to `part`
+// for the next layer to add up in the fixed order.  The part's k-blocks start at a wave-uniform RUNTIME index: afrag(kb) and the weight
+// offset take it as a scalar; all of the part's weight k-blocks are requested up front by ksplit_load (KB / NSH registers of four: the
+// caller issues it a layer early, so that the L2 round trip is over when the barrier in front of this layer opens), the activation
+// fragments run one k-block ahead.
+template <int KB, int NSH>            // the weight k-blocks of part `kpart` of column tile nt, requested (by the caller: a layer EARLY, behind no barrier)
+__device__ __forceinline__ void ksplit_load(const WBuf &wb, int wbase, int nt, int kpart, f32x4 (&bq)[KB / NSH]) {
+    const int w0 = wbase + (nt * KB + kpart * (KB / NSH)) * 256;
+#pragma unroll
+    for (int j = 0; j < KB / NSH; j++) bq[j] = wb.load(w0 + j * 256);
+}
+template <int KB, int NSEG, int NSH, typename AFrag>
+__device__ __forceinline__ void gemm_ksplit(const f32x4 (&bq)[KB / NSH], int kpart, AFrag afrag, float *part /* [NSEG][256] of this (tile, nt) */) {
+    constexpr int SPW = NSEG / NSH, KBP = KB / NSH;
+    static_assert(NSEG % NSH == 0 && KB % NSH == 0, "whole segments, equal parts");
+    constexpr auto seg_lo = [](int c) { return (KB * c) / NSEG; };
+    static_assert([&]() { for (int p = 1; p < NSH; p++) for (int c = 0; c <= SPW; c++) if (seg_lo(p * SPW + c) - seg_lo(p * SPW) != seg_lo(c) - seg_lo(0)) return false; return true; }(),
+                  "every part's segments have the lengths of the first part's");
+    static_assert(seg_lo(SPW) == KBP, "a part is KB / NSH k-blocks");
+    const int lane = threadIdx.x & 63;
+    const int kb0 = kpart * KBP;                                        // wave-uniform
+    f32x4 accx[SPW];
+#pragma unroll
+    for (int c = 0; c < SPW; c++) accx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a[2];
+    a[0] = afrag(kb0);
+#pragma unroll
+    for (int j = 0; j < KBP; j++) {
+        int seg = 0;                                                    // the segment (of this part) k-block j belongs to: static after unrolling
+#pragma unroll
+        for (int c = 1; c < SPW; c++) seg += j >= seg_lo(c) ? 1 : 0;
+        if (j + 1 < KBP) a[(j + 1) & 1] = afrag(kb0 + j + 1);
+        const f32x4 b = bq[j];
+#pragma unroll
+        for (int q = 0; q < 4; q++) accx[seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[q], a[j & 1][q], accx[seg], 0, 0, 0);   // D^T: see tile_out
+    }
+#pragma unroll
+    for (int c = 0; c < SPW; c++) *reinterpret_cast<f32x4 *>(&part[(kpart * SPW + c) * 256 + lane * 4]) = accx[c];   // D-fragment order: [segment][lane][reg]
+}
+
 // The same share-out for the SHORT 32-column layers (the blocks' first 1x1, K = 64): there a reduction pass and its two
 // barriers cost more than the imbalance they remove, so the last row tile is not k-split but computed whole by the wave of
 // each column tile whose share comes last (kpart == NSPLIT - 1).  No tile of these layers is split, so every output is one
@@ -393,7 +453,8 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                                                              float *__restrict__ logits_out, double *__restrict__ p_out,
                                                              float *__restrict__ v_out, const uint16_t *__restrict__ moves) {
     constexpr int NB = C::NB, NTH = C::NTH, ROWS = C::ROWS, MT = C::MT, NSPLIT = C::NSPLIT, PADROWS = C::PADROWS, INROWS = C::INROWS,
-                  NW = C::NW, F32 = C::F32, F64 = C::F64, M64 = C::M64, XT = C::XT, HB = C::HB;
+                  NW = C::NW, F32 = C::F32, F32A = C::F32A, F64 = C::F64, M64 = C::M64, XT = C::XT, HB = C::HB;
+    constexpr bool AS = C::ALLSPLIT;                              // <1, 8>: every 3x3 tile job is shared by NSH waves (see Cfg)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem<C> &S = *reinterpret_cast<Smem<C> *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -479,8 +540,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     if (blockIdx.x == 0 && threadIdx.x == 0) net_stamps[60] = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    const int nt2 = wave & 1, qr = wave >> 1, mt3 = F32 * qr;    // this wave's share of the 32-column layers (see below)
+    const int nt2 = wave & 1, qr = wave >> 1, mt3 = AS ? qr % MT : F32 * qr;    // this wave's share of the 32-column layers (see below; AS: its ONE row tile)
     const int kshare = XT ? qr : -1;                             // its share of the last tile's k-range (none in a shape without one)
+    const int kh = AS ? qr / MT : 0;                             // AS: its part of the tile's k-range in the 3x3 layers; part 0 computes the tile in the first 1x1
     f32x4 pre[NPREMAX];                                          // the next layer's first weight k-blocks, in flight across barriers
     auto bias4 = [&](int off) -> f32x4 { return *reinterpret_cast<const f32x4 *>(W + off + 4 * q); };   // this lane's four output channels
     auto relu4 = [](const f32x4 &v) -> f32x4 { return f32x4{relu(v[0]), relu(v[1]), relu(v[2]), relu(v[3])}; };
@@ -524,17 +586,17 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     // Per slot (0-2: the full tiles; 3: tile 12), once for all nine blocks:
     //   a3[i]     element offset in y1 of the row's TOP-LEFT tap (zero-halo copy): tap (dr, dc) is + (dr*6 + dc) * LDY
     //   prow[i]   element offset in y1 of the interior cell of this lane's row of tile i (1x1 epilogue -> 3x3 input)
-    int a3[F32 + 1], prow[F32];
-    bool prow_ok[F32];                                         // (PADFULL shapes: is this lane's row of the tile a real cell?)
+    int a3[F32A + 1], prow[F32A];
+    bool prow_ok[F32A];                                        // (PADFULL shapes: is this lane's row of the tile a real cell?)
 #pragma unroll
-    for (int i = 0; i < F32 + 1; i++) {
-        int row = (i < F32 ? mt3 + i : MT - 1) * 16 + l15;
+    for (int i = 0; i < F32A + 1; i++) {
+        int row = (i < F32A ? mt3 + i : MT - 1) * 16 + l15;
         if (row >= ROWS) row -= 25;                            // padding rows of the last tile: any valid cell (results never read)
         const int s = row / 25, pos = row % 25;
         a3[i] = (s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;              // = cell (r - 1, c - 1): PAD0 - 7 = 0
     }
 #pragma unroll
-    for (int i = 0; i < F32; i++) {
+    for (int i = 0; i < F32A; i++) {
         int row = (mt3 + i) * 16 + l15;                        // <8,8>, <4,4>: always a real cell
         prow_ok[i] = row < ROWS;
         if (row >= ROWS) row -= 25;
@@ -549,6 +611,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     }
 
     // ---- nine bottleneck residual blocks (model.py:120-145) ------------------------------------------
+    f32x4 bq2[AS ? 18 / C::NSH : 1];                             // (AS: this wave's weight k-blocks of the block's 3x3 layer)
     for (int blk = 0; blk < 9; blk++) {
         {   // 1x1 64 -> 32: 2 column tiles x 4 row groups of three tiles + a quarter of tile 12's k-range each
             auto afrag = [&](int mt, int kb, int) -> f32x4 {
@@ -556,16 +619,25 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             };
             const f32x4 bv = bias4(LAY.l1_b[blk] + nt2 * 16);
             auto epi = [&](int, const f32x4 &acc, int i) {
-                const int at = i == 0 ? prow[0] : (i == 1 ? prow[F32 > 1 ? 1 : 0] : prow[F32 > 2 ? 2 : 0]);
+                const int at = i == 0 ? prow[0] : (i == 1 ? prow[F32A > 1 ? 1 : 0] : prow[F32A > 2 ? 2 : 0]);
                 if constexpr (C::PADFULL) {
-                    if (!(i == 0 ? prow_ok[0] : (i == 1 ? prow_ok[F32 > 1 ? 1 : 0] : prow_ok[F32 > 2 ? 2 : 0]))) return;
+                    if (!(i == 0 ? prow_ok[0] : (i == 1 ? prow_ok[F32A > 1 ? 1 : 0] : prow_ok[F32A > 2 ? 2 : 0]))) return;
                 }
                 *reinterpret_cast<f32x4 *>(&S.y1[at + nt2 * 16]) = relu4(acc + bv);
             };
             auto epix = [&](const f32x4 &acc) {                                 // the last tile: its real rows only
                 if (l15 < ROWS - (MT - 1) * 16) *reinterpret_cast<f32x4 *>(&S.y1[prowx + nt2 * 16]) = relu4(acc + bv);
             };
-            gemm_tiles_last<F32, 4, NSPLIT, CCSP_NET_SEG_L1>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); },
+            if constexpr (AS) ksplit_load<18, C::NSH>(wb, LAY.l2_w[blk], nt2, kh, bq2);      // the 3x3 layer's weights: in flight across this layer
+            if constexpr (AS) {
+                // one tile job per (row tile, column tile): the wave with part 0 of the tile's k-range in the 3x3 layer computes it whole
+                // here (a plain chain over k like every other shape's); the 3x3 layer requests its own weights
+                auto epi1 = [&](int, const f32x4 &acc, int) {
+                    if (prow_ok[0]) *reinterpret_cast<f32x4 *>(&S.y1[prow[0] + nt2 * 16]) = relu4(acc + bv);
+                };
+                if (kh == 0) gemm_tiles<1, 4, CCSP_NET_SEG_L1>(wb, LAY.l1_w[blk], nt2, mt3, pre, afrag, []() {}, epi1);
+            } else
+            gemm_tiles_last<F32A, 4, NSPLIT, CCSP_NET_SEG_L1>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); },
                                             epi, epix);
         }
         __syncthreads();
@@ -579,7 +651,15 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             auto epi = [&](int mt, const f32x4 &acc, int i) {
                 *reinterpret_cast<f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + nt2 * 16 + 4 * q]) = relu4(acc + bv);
             };
-            gemm_tiles_split<F32, 18, C::NSEG, NSPLIT>(wb, LAY.l2_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
+            if constexpr (AS) {
+                auto afrag_rt = [&](int kb) -> f32x4 {                           // (kb: wave-uniform, known at run time)
+                    const int tap = kb >> 1;
+                    return *reinterpret_cast<const f32x4 *>(&S.y1[a3[0] + ((tap / 3) * 6 + tap % 3) * LDY + (kb & 1) * 16]);
+                };
+                gemm_ksplit<18, C::NSEG, C::NSH>(bq2, kh, afrag_rt, &S.part[mt3 * 2 + nt2][0][0]);
+                prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre);
+            } else
+            gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT>(wb, LAY.l2_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
                                                        &S.part[nt2][0][0]);
             NET_STAMP(32 + blk);                             // diagnostic: wave 0 done with its share of the 3x3 layer
 #ifdef CCSP_STAMPS
@@ -596,14 +676,15 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             // The 3x3 layer's k-split tile (MT - 1) is consumed straight from its partial sums -- no reduction pass, no two extra
             // barriers: part[nt2][c][lane * 4 + j] is, for THIS lane's (row, k-slot), exactly what an activation fragment of
             // k-block nt2 holds, so the waves whose share ends with that tile form ((c0 + c1) + c2) + c3 + bias, ReLU in registers.
-            const bool has_x = XT && mt0 + F64 - 1 == MT - 1;               // wave-uniform
+            const bool has_x = AS || (XT && mt0 + F64 - 1 == MT - 1);       // wave-uniform (AS: EVERY tile of the 3x3 layer arrives as partial sums)
+            const int xt = AS ? mt0 : 0;                                    // which of the Smem::part tiles
             f32x4 ax[2];
             if (has_x) {
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++) {
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(&S.part[kb][0][lane * 4]);
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(&S.part[xt * 2 + kb][0][lane * 4]);
 #pragma unroll
-                    for (int c = 1; c < C::NSEG; c++) v = v + *reinterpret_cast<const f32x4 *>(&S.part[kb][c][lane * 4]);
+                    for (int c = 1; c < C::NSEG; c++) v = v + *reinterpret_cast<const f32x4 *>(&S.part[xt * 2 + kb][c][lane * 4]);
                     ax[kb] = relu4(v + bias4(LAY.l2_b[blk] + kb * 16));
                 }
             }
@@ -665,7 +746,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     // every logit is ((q0 + q1) + q2) + q3 + bias -- the same chains for every position, whatever its slot or the workgroup shape.
     float *part = S.x;                                   // [4][HB][320] partial sums
     {
-        constexpr int GPQ = 25, NHALF = NW / 4, TPW = (5 + NHALF - 1) / NHALF, PG = HB / 4, PDG = CCSP_NET_PDG;
+        constexpr int GPQ = 25, NHALF = NW / 4, TPW = (5 + NHALF - 1) / NHALF, PG = HB / 4, PDG = C::PDG;
         const int kq = wave & 3, th = wave >> 2;
         int woff[TPW];
         bool valid[TPW];
@@ -833,6 +914,10 @@ static int g_net_shape = 0;                   // positions per workgroup: 8 (one
 #define CCSP_NET_SMALL 1024                   // batches up to this many positions run in the <4, 4> shape (see ccsp_net_forward)
 #define CCSP_NET_TINY 512                     // ... and up to this many in the <2, 8> shape
 #endif
+#ifndef CCSP_NET_ONE
+#define CCSP_NET_ONE 256                      // ... and up to this many (one workgroup per CU) in the <1, 8> shape
+#endif
+static int pick_shape(int n) { return n <= CCSP_NET_ONE ? 1 : (n <= CCSP_NET_TINY ? 2 : (n <= CCSP_NET_SMALL ? 4 : 8)); }
 
 extern "C" {
 
@@ -890,20 +975,21 @@ int ccsp_net_pack(const float *plain, float *packed) {
 // Test / measurement hook: pick the workgroup shape of ccsp_net_forward (8 or 4 positions per workgroup; anything else
 // restores the default).  Both shapes compute every position with the same arithmetic in the same order: results are identical.
 int ccsp_debug_net_shape(int positions_per_workgroup) {
-    g_net_shape = (positions_per_workgroup == 2 || positions_per_workgroup == 4 || positions_per_workgroup == 8) ? positions_per_workgroup : 0;
+    g_net_shape = (positions_per_workgroup == 1 || positions_per_workgroup == 2 || positions_per_workgroup == 4 || positions_per_workgroup == 8) ? positions_per_workgroup : 0;
     return g_net_shape;
 }
 
 int ccsp_net_forward(const float *packed, const float *planes, int n, float *logits, double *p, float *v, void *stream) {
     if (n < 0 || (n > 0 && (!packed || !planes || !v))) return CCSP_EINVAL;
     if (n == 0) return CCSP_OK;
-    static bool attr8[64] = {false}, attr4[64] = {false}, attr2[64] = {false};
+    static bool attr8[64] = {false}, attr4[64] = {false}, attr2[64] = {false}, attr1[64] = {false};
     // All shapes compute a position with the same arithmetic in the same order (bit-identical results), so the choice is one of speed
     // only.  While a batch does not fill the 256 CUs its launch is as long as ONE workgroup (tools/bench_net_sizes.py): 116-119 us in
     // <8, 8> for 1 .. 2048 positions, 75-77 us in <4, 4> up to 1024 (4 positions on 4 waves), 46-48 us in <2, 8> up to 512 (2 positions on 8
     // waves: one tile job per wave in the 32-column layers) -- the arena's 24 games, one game of selfplay(), config 5's small cohorts.
     // Large batches want <8, 8>: the policy dense layer's weights cross L2 once per 8 positions.
-    const int shape = g_net_shape ? g_net_shape : (n <= CCSP_NET_TINY ? 2 : (n <= CCSP_NET_SMALL ? 4 : 8));
+    const int shape = g_net_shape ? g_net_shape : pick_shape(n);
+    if (shape == 1) return launch_net<Cfg<1, 8>>(packed, planes, n, logits, p, v, stream, attr1);
     if (shape == 2) return launch_net<Cfg<2, 8>>(packed, planes, n, logits, p, v, stream, attr2);
     if (shape == 4) return launch_net<Cfg<4, 4>>(packed, planes, n, logits, p, v, stream, attr4);
     return launch_net<Cfg<8, 8>>(packed, planes, n, logits, p, v, stream, attr8);
@@ -912,9 +998,10 @@ int ccsp_net_forward(const float *packed, const float *planes, int n, float *log
 int ccsp_net_forward_requests(const float *packed, const ccsp_request *req, const uint16_t *moves, int n, double *pk, float *v, void *stream) {
     if (n < 0 || (n > 0 && (!packed || !req || !moves || !pk || !v))) return CCSP_EINVAL;
     if (n == 0) return CCSP_OK;
-    static bool attr8[64] = {false}, attr4[64] = {false}, attr2[64] = {false};
+    static bool attr8[64] = {false}, attr4[64] = {false}, attr2[64] = {false}, attr1[64] = {false};
     const float *in = reinterpret_cast<const float *>(req);
-    const int shape = g_net_shape ? g_net_shape : (n <= CCSP_NET_TINY ? 2 : (n <= CCSP_NET_SMALL ? 4 : 8));
+    const int shape = g_net_shape ? g_net_shape : pick_shape(n);
+    if (shape == 1) return launch_net<Cfg<1, 8>, true>(packed, in, n, nullptr, pk, v, stream, attr1, moves);
     if (shape == 2) return launch_net<Cfg<2, 8>, true>(packed, in, n, nullptr, pk, v, stream, attr2, moves);
     if (shape == 4) return launch_net<Cfg<4, 4>, true>(packed, in, n, nullptr, pk, v, stream, attr4, moves);
     return launch_net<Cfg<8, 8>, true>(packed, in, n, nullptr, pk, v, stream, attr8, moves);

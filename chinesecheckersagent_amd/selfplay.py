@@ -672,9 +672,12 @@ class SelfPlayRun(object):
         cap = n_slots * (self.harvest_every + 1)
         if free_running is None:
             # a batch that does not fill the GPU is latency-bound: a lock-step round (net -> one tree kernel) is shorter than a
-            # free-running one (256 games x 800 simulations: 7.6 s lock-step, 8.4-8.6 s free-running although a quarter of the
-            # expansions come from the previous tree); from about a thousand slots on the free-running form wins (4096: +19 %)
-            free_running = n_slots >= 1024
+            # free-running one (net -> advance -> boundary) -- measured in steady state at 800 simulations with the <1,8> evaluator shape,
+            # k node-expansions/s lock-step / free-running: 1 slot 22.7 / 24.9, 8 slots 166 / 173, 24 slots 488 / 489, 64 slots 1283 /
+            # 1194, 256 slots 4954 / 4219 (a sixth to a fifth of the free-running expansions come from the previous tree; its round is
+            # 48 us against 43 for one slot, 72 against 52 for 256) -- so: free-running for a handful of slots (one game of selfplay():
+            # the reused positions are worth more than the longer round) and from about a thousand on (4096: +30 %), lock-step between
+            free_running = n_slots >= 1024 or (n_slots <= 8 and model2 is None)
         if free_running and hasattr(_batched(model1), 'model'):
             # slots run at their own pace (BatchSelfPlay): between two harvests a slot plays up to ~1.5 plies per `play_ply`; a slot that
             # could find the log full waits for the harvest (log_guard) instead of losing a row

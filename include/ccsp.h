@@ -357,9 +357,9 @@ int ccsp_net_forward(const float *packed, const float *planes, int n, float *log
  * by ccsp_gather_priors.  Rows with kind == 0 are evaluated on an all-zero input and not written. */
 int ccsp_net_forward_requests(const float *packed, const ccsp_request *req, const uint16_t *moves, int n, double *pk, float *v, void *stream);
 
-/* test / measurement hook: workgroup shape of ccsp_net_forward -- 8, 4 or 2 positions per workgroup; any other value restores the
- * default: by batch size (batches that cannot fill the GPU run in the shape whose single workgroup is done sooner: 2 up to 512
- * positions, 4 up to 1024, 8 beyond).  Bit-identical results in every shape.  Returns the value in force (0 = by batch size). */
+/* test / measurement hook: workgroup shape of ccsp_net_forward / ccsp_net_forward_requests -- 8, 4, 2 or 1 positions per workgroup; any other
+ * value restores the default: by batch size (batches that cannot fill the GPU run in the shape whose single workgroup is done sooner: 1 up
+ * to 256 positions, 2 up to 512, 4 up to 1024, 8 beyond).  Bit-identical results in every shape.  Returns the value in force (0 = by batch size). */
 int ccsp_debug_net_shape(int positions_per_workgroup);
 
 /* ---- read-back (synchronous; host buffers unless said otherwise) ----------------------------------- */

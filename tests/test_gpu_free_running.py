@@ -263,7 +263,7 @@ def test_requests_evaluated_in_place_equal_planes_evaluated(golden_dir):
     m.load_weights(golden_dir + '/good_model.h5')
     assert m.backend == 'hip'
     rng = np.random.RandomState(5)
-    for n in (1, 2, 3, 8, 19, 515, 1027, 2048):
+    for n in (1, 2, 3, 8, 19, 256, 515, 1027, 2048):
         pick = rng.choice(len(pos12), n, replace=len(pos12) < n)
         states = _lib.pack_states(pos12[pick], last[pick])
         pl = player[pick].astype(np.uint8)
@@ -281,7 +281,7 @@ def test_requests_evaluated_in_place_equal_planes_evaluated(golden_dir):
         d_mv = torch.from_numpy(moves.view(np.int16)).cuda()
         want_pk, want_v = evaluate_requests_with(m.evaluate_batch, d_req, d_mv)
         asks = torch.from_numpy(req['kind'] != 0).cuda()
-        for shape in (0, 8, 4, 2):
+        for shape in (0, 8, 4, 2, 1):
             L.ccsp_debug_net_shape(shape)
             try:
                 pk = torch.full((n, _lib.REQUEST_MOVES), -7.0, dtype=torch.float64, device='cuda')

@@ -225,14 +225,16 @@ def test_gpu_evaluation_is_a_function_of_the_position_alone(net, golden_dir):
     ref64 = net['logits_good_model'][:3]
     try:
         want = None                                    # ONE expectation for every shape: the shapes agree bit for bit, too
-        for shape in (8, 4, 2, 0):                     # 0 = chosen by batch size: <2,8> up to 512 positions, <4,4> up to 1024, <8,8> beyond
+        for shape in (8, 4, 2, 1, 0):                  # 0 = chosen by batch size: <1,8> up to 256 positions, <2,8> up to 512, <4,4> up to 1024, <8,8> beyond
             assert L.ccsp_debug_net_shape(shape) == shape
-            for n in (3, 16, 19, 51) + ((512, 515, 1024, 1027) if shape == 0 else ()):
+            for n in (1, 3, 16, 19, 51) + ((256, 257, 512, 515, 1024, 1027) if shape == 0 else ()):
                 idx = torch.arange(n, device='cuda') % 3
                 lg, v = m.predict_batch(base[idx].contiguous())
                 p, _ = m.evaluate_batch(base[idx].contiguous())
                 for k in range(3):
                     rows = (idx == k).nonzero().flatten()
+                    if len(rows) == 0:
+                        continue
                     if want is None:
                         want = [None, None, None]
                     if want[k] is None:

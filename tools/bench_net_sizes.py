@@ -11,12 +11,14 @@ L = _lib.lib()
 m = ResidualCNN(); m.load_weights('tests/golden/good_model.h5')
 packed = m._ensure_packed()
 st = _stream_ptr()
-print('%8s %12s %12s %12s' % ('n', '<8,8> us', '<4,4> us', '<2,8> us'))
-for n in (1, 4, 8, 24, 64, 128, 256, 512, 768, 1024, 1280, 1536, 2048, 4096):
+print('%8s %12s %12s %12s %12s' % ('n', '<8,8> us', '<4,4> us', '<2,8> us', '<1,8> us'))
+import os
+SIZES = (1, 64, 256, 512) if os.environ.get('SMALL_ONLY') else (1, 4, 8, 24, 64, 128, 256, 384, 512, 768, 1024, 1280, 1536, 2048, 4096)
+for n in SIZES:
     x = torch.rand((n, 343), device='cuda')
     p = torch.empty((n, 294), dtype=torch.float64, device='cuda'); v = torch.empty(n, dtype=torch.float32, device='cuda')
     row = []
-    for shape in (8, 4, 2):
+    for shape in (8, 4, 2, 1):
         L.ccsp_debug_net_shape(shape)
         for _ in range(50):
             L.ccsp_net_forward(packed.data_ptr(), x.data_ptr(), n, None, p.data_ptr(), v.data_ptr(), st)
@@ -26,5 +28,5 @@ for n in (1, 4, 8, 24, 64, 128, 256, 512, 768, 1024, 1280, 1536, 2048, 4096):
             L.ccsp_net_forward(packed.data_ptr(), x.data_ptr(), n, None, p.data_ptr(), v.data_ptr(), st)
         b.record(); torch.cuda.synchronize()
         row.append(a.elapsed_time(b) / 200 * 1e3)
-    print('%8d %12.1f %12.1f %12.1f' % (n, row[0], row[1], row[2]))
+    print('%8d %12.1f %12.1f %12.1f %12.1f' % (n, row[0], row[1], row[2], row[3]))
 L.ccsp_debug_net_shape(0)

@@ -48,9 +48,11 @@ if what in ('all', 'fused'):
     e.close()
 if what in ('all', 'free'):         # the free-running stepped path on PLAIN launches (no hipGraph under --pmc): net_forward_kernel beside
     m = ResidualCNN(); m.load_weights('tests/golden/good_model.h5')     # advance_kernel / boundary_kernel at 4096 slots x 400 simulations
-    run = sp.SelfPlayRun(m, n_games=4096 * 8, sims=400, seed=bench.SEED, max_slots=4096, keep_records=False, use_graph=False)
+    # (every slot starts at once -- stagger span of one boundary call -- so that the launches the aggregator keeps, the LAST THIRD of
+    # each kernel's, are the steady state: all 2048 slots of a half-batch searching, reused positions, ply ends and roots included)
+    run = sp.SelfPlayRun(m, n_games=4096 * 8, sims=400, seed=bench.SEED, max_slots=4096, keep_records=False, use_graph=False, stagger_span=6)
     for b in (run.b.parts if hasattr(run.b, 'parts') else [run.b]):
-        b.play_steps(int(sys.argv[2]) if len(sys.argv) > 2 else 700)      # (700: one and a half plies of every slot: reused positions, ply ends and roots included)
+        b.play_steps(int(sys.argv[2]) if len(sys.argv) > 2 else 1300)     # (1300 rounds: three plies of every slot)
     torch.cuda.synchronize()
     print('free-running: counters', run.counters())
     run.close()

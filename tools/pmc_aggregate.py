@@ -22,6 +22,8 @@ for (k, c), vs in sorted(rows.items()):
     big = [v for v in vs if v[0] == g]
     if len(big) > 2:
         big = big[1:]                          # the first launch of a size is cold
+    if len(big) > 300:
+        big = big[len(big) * 2 // 3:]          # a long run (tools/kernels_once.py `free`): its last third = the steady state
     o = out.setdefault(k, dict(big[0][3], grid_threads=g))
     o[c] = sum(v[1] for v in big) / len(big)
     o.setdefault('launches', {})[c] = len(big)
