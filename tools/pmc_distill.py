@@ -14,7 +14,8 @@ src = ('profiles/%s (rocprofv3 --pmc, one counter set per pass with --kernel-tra
        'known exactly)' % name)
 LANES = {'movegen_kernel<false>': 2, 'movegen_kernel<true>': 2, 'movegen_kernel<false, true>': 2, 'step_kernel': 1, 'encode_kernel': 4}     # threads per state
 # round 3: the kernel has a second template flag (PACKED); counters.json keeps its keys: <false> = rows, <false, true> = packed, <true> = greedy
-RENAME = {'movegen_kernel<false, false>': 'movegen_kernel<false>', 'movegen_kernel<true, false>': 'movegen_kernel<true>'}
+RENAME = {'movegen_kernel<false, false>': 'movegen_kernel<false>', 'movegen_kernel<true, false>': 'movegen_kernel<true>',
+          'advance_kernel<false>': 'advance_kernel', 'encode_kernel<false>': 'encode_kernel'}      # (round 5: template flags DBG / REQ)
 for k, x in list(d.items()):
     k = RENAME.get(k, k)
     if only and k not in only:
