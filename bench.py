@@ -8,7 +8,7 @@ Headline workload (BASELINE.json configs[2], SURVEY.md §8d config 3 -- the conf
 node-expansions/s at 4096 games x 400 sims" is quoted on): 4096 concurrent games per GPU, 400 simulations per move,
 good_model.h5 through the fused fp32-MFMA evaluator kernel, played THROUGH THE DELIVERED API (selfplay.SelfPlayRun, what
 selfplay_batch / generate_self_play / generate_train_data run on): restarting slots in steady state, two half-batches on two
-HIP streams, 25 simulation steps per hipGraph, the sample log harvested every 16 plies and converted to (board_x, pi_y, v_y)
+HIP streams, 25 rounds per hipGraph, the sample log harvested every 2 steps and converted to (board_x, pi_y, v_y)
 by a worker thread while the GPU plays on.  One STEP = one ply of every slot = 4096 x (1 root expansion + 400 simulations).
 The timed region holds K steps, the conversion of every game that ended in it and the training file they are streamed into
 (utils.save_train_data's datasets, chunked: selfplay.TrainDataSink(path)).  `value` = whole-job node-expansions/s (one expansion = one evaluator call, MCTS.py:93); games/s,
@@ -439,7 +439,7 @@ def main():
     ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
     ap.add_argument('--sims', type=int, default=400)
     ap.add_argument('--spread-plies', type=int, default=72, help='untimed plies before the warm-up: the first cohort of games spreads out')
-    ap.add_argument('--harvest-every', type=int, default=4)
+    ap.add_argument('--harvest-every', type=int, default=2)
     ap.add_argument('--min-seconds', type=float, default=1.0, help='shortest timed region: K more steps are added until it is reached')
     ap.add_argument('--fused-plies', type=int, default=192, help='variant 2a: timed plies of the fused kernel')
     ap.add_argument('--no-extras', action='store_true', help='headline region only: no variants, config 5, cpu baseline')

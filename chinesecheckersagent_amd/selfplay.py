@@ -633,8 +633,9 @@ class GameStore(object):
 
 
 MAX_SLOTS = 4096          # concurrent games per GPU (BASELINE.json); more games than this restart in the slots that come free
-HARVEST_EVERY = 4         # plies between two harvests of the sample log (a harvest costs the run 0.3 % at 8 and no more at 2;
-                          # the shorter the interval, the less is left to convert when a run ends)
+HARVEST_EVERY = 2         # steps between two harvests of the sample log (a harvest costs the run 0.3 % at 8 and no more at 2; the
+                          # shorter the interval, the less is left to convert when a run ends: at the end of a 20-step region 22 ms
+                          # against 37-51 ms with 4 -- +0.5-1 % of node-expansions/s over such a region, measured in round 5)
 
 
 class SelfPlayRun(object):

@@ -438,6 +438,18 @@ def test_free_running_slots_play_the_lock_step_games(golden_dir):
     got = _records(b.run_to_completion(max_plies=1100))
     b.close()
     assert got == want
+    # ccsp_boundary on a stream of its own beside the next evaluator launch (CCSP_ADVANCE_OVERLAPPED: a root request is then answered by
+    # the launch after the next): plain launches and a captured graph with the fork in it -- the same games
+    sp.BatchSelfPlay.SIDE_STREAM = True
+    try:
+        for graph in (False, True):
+            b = sp.BatchSelfPlay(m, n_slots=n, sims=sims, seed=seed, first_game=first, max_games=n, log_capacity=n * 600, free_running=True, reuse=True,
+                                 use_graph=graph)
+            got = _records(b.run_to_completion(max_plies=1100))
+            b.close()
+            assert got == want, ('side stream', graph)
+    finally:
+        sp.BatchSelfPlay.SIDE_STREAM = False
     # the diagnostic build of the kernel (per-phase stamps, tools/bench_free.py --debug) plays the same games and accounts for every call
     sp.BatchSelfPlay.DEBUG = True
     try:
