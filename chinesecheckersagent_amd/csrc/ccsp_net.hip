@@ -41,6 +41,9 @@ constexpr int LDX = CCSP_NET_LDX;        // row stride of the 64-channel buffer 
 constexpr int LDY = CCSP_NET_LDY;        // row stride of the 32-channel buffers
 constexpr int LDI = 12;                  // input planes: 7 channels + zeros; 12 spreads eight consecutive cells over all banks
 constexpr int NPOL = 294, NPOL_PAD = 304;
+#ifndef CCSP_NET_LDS_BIAS_ALL
+#define CCSP_NET_LDS_BIAS_ALL 0          // 1: the trunk's biases through LDS in <8,8> too (see bias4 in the kernel)
+#endif
 #ifndef CCSP_NET_PDG
 #define CCSP_NET_PDG 1                   // policy dense: groups of four k the weight loads run ahead
 #endif
@@ -68,6 +71,7 @@ constexpr int NPOL = 294, NPOL_PAD = 304;
 
 // ---- packed weight blob layout (floats) ----------------------------------------------------------------
 struct Layout {
+    int trunk_b;
     int stem_w, stem_b;
     int l1_w[9], l1_b[9], l2_w[9], l2_b[9], l3_w[9], l3_b[9];
     int pc_w, pc_b, pf_w, pf_b;
@@ -79,13 +83,16 @@ constexpr Layout make_layout() {
     Layout L{};
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-    L.stem_w = take(4 * 5 * 256); L.stem_b = take(64);
+    // the trunk's biases stand TOGETHER (stem 64 | per block 32, 32, 64 | policy conv 16: the order of Smem::bias, BIAS_* below), so that
+    // a workgroup copies them into LDS with one 16-byte load per thread
+    L.trunk_b = take(64 + 9 * 128 + 16);
+    L.stem_w = take(4 * 5 * 256); L.stem_b = L.trunk_b;
     for (int i = 0; i < 9; i++) {
-        L.l1_w[i] = take(2 * 4 * 256); L.l1_b[i] = take(32);
-        L.l2_w[i] = take(2 * 18 * 256); L.l2_b[i] = take(32);
-        L.l3_w[i] = take(4 * 2 * 256); L.l3_b[i] = take(64);
+        L.l1_w[i] = take(2 * 4 * 256); L.l1_b[i] = L.trunk_b + 64 + i * 128;
+        L.l2_w[i] = take(2 * 18 * 256); L.l2_b[i] = L.trunk_b + 64 + i * 128 + 32;
+        L.l3_w[i] = take(4 * 2 * 256); L.l3_b[i] = L.trunk_b + 64 + i * 128 + 64;
     }
-    L.pc_w = take(1 * 4 * 256); L.pc_b = take(16);
+    L.pc_w = take(1 * 4 * 256); L.pc_b = L.trunk_b + 64 + 9 * 128;
     L.pf_w = take(5 * 100 * 256); L.pf_b = take(NPOL_PAD);      // [tile of 64 columns][group of 4 k][lane = column][k]
     L.vc_w = take(64); L.vc_b = take(1);
     L.f1_w = take(25 * 32); L.f1_b = take(32);
@@ -94,6 +101,22 @@ constexpr Layout make_layout() {
     return L;
 }
 constexpr Layout LAY = make_layout();
+// The nine blocks' entries are equally spaced in the blob: inside the block loop an offset is l*_x[0] + blk * BLK_STRIDE -- scalar
+// arithmetic -- instead of a look-up of the table in constant memory (an s_load and an `s_waitcnt lgkmcnt(0)` -- which also waits
+// for every LDS read in flight -- in the middle of a layer's MFMA stream, six times per block).
+constexpr int BLK_STRIDE = LAY.l1_w[1] - LAY.l1_w[0];
+constexpr bool layout_is_regular() {
+    for (int i = 0; i < 9; i++)
+        if (LAY.l1_w[i] != LAY.l1_w[0] + i * BLK_STRIDE || LAY.l2_w[i] != LAY.l2_w[0] + i * BLK_STRIDE || LAY.l3_w[i] != LAY.l3_w[0] + i * BLK_STRIDE) return false;
+    return true;
+}
+static_assert(layout_is_regular(), "the blocks' weights are BLK_STRIDE floats apart");
+// The trunk's biases in LDS (Smem::bias): stem 64 | per block: first 1x1 32, 3x3 32, last 1x1 64 | policy conv 16.  An epilogue that
+// reads its bias from global memory waits with `s_waitcnt vmcnt(0)` -- for the bias AND for the next layer's weight k-blocks that were
+// requested a moment earlier (an L2 round trip, exposed in the wave whose epilogue nothing hides: seen in the listing, round 5).
+constexpr int BIAS_STEM = 0, BIAS_BLK = 64, BIAS_PER_BLK = 128, BIAS_L1 = 0, BIAS_L2 = 32, BIAS_L3 = 64, BIAS_PC = BIAS_BLK + 9 * BIAS_PER_BLK, BIAS_N = BIAS_PC + 16;
+static_assert(LAY.stem_b == LAY.trunk_b + BIAS_STEM && LAY.l1_b[3] == LAY.trunk_b + BIAS_BLK + 3 * BIAS_PER_BLK + BIAS_L1 && LAY.l2_b[8] == LAY.trunk_b + BIAS_BLK + 8 * BIAS_PER_BLK + BIAS_L2 &&
+              LAY.l3_b[0] == LAY.trunk_b + BIAS_BLK + BIAS_L3 && LAY.pc_b == LAY.trunk_b + BIAS_PC && BIAS_N % 4 == 0 && LAY.trunk_b % 4 == 0, "Smem::bias is the blob's trunk_b region");
 
 // plain (Keras-order, BatchNorm already folded) input of ccsp_net_pack: offsets in floats
 constexpr int PLAIN_TOTAL = 4032 + 64 + 9 * (2048 + 32 + 9216 + 32 + 2048 + 64) + 1024 + 16 + 117600 + 294 + 64 + 1 + 800 + 32 + 32 + 1;
@@ -159,12 +182,13 @@ struct Smem {
     static constexpr int Y2N = Y2A > Y2B ? (Y2A > Y2C ? Y2A : Y2C) : (Y2B > Y2C ? Y2B : Y2C);
     float y2[Y2N];                       // 32-channel 3x3 output; the stem's input planes and the logits / value scratch alias it
     float part[2 * C::XTILES][C::NSEG][256];   // partial sums (one per k-segment) of the k-split row tiles of the 3x3 layers: [tile * 2 + column tile]
+    float bias[(C::NB < 8 || CCSP_NET_LDS_BIAS_ALL) ? BIAS_N : 4];  // the trunk's biases (see BIAS_*): read by the epilogues through LDS in the small shapes
     static_assert(C::INROWS * LDI <= Y2N, "the staged input planes alias y2");
     static_assert(C::MT * 16 * 16 <= C::PADROWS * LDY && C::HB * 400 <= C::PADROWS * LDY, "the policy conv output aliases y1");
     static_assert(256 + C::HB * (NPOL_PAD + 32) <= Y2N, "logits and value scratch alias y2");
 };
 static_assert(sizeof(Smem<Cfg<8, 8>>) + 3 * 6900 <= 160 * 1024, "<8,8>: one evaluator workgroup per CU plus three tree-kernel workgroups");
-static_assert(2 * sizeof(Smem<Cfg<4, 4>>) + 7800 <= 160 * 1024, "<4,4>: two evaluator workgroups per CU plus a tree-kernel workgroup");
+static_assert(sizeof(Smem<Cfg<4, 4>>) + 3 * 6900 <= 160 * 1024, "<4,4>: an evaluator workgroup per CU plus three tree-kernel workgroups (two per CU no longer fit: the shape carries batches of at most one workgroup per CU)");
 static_assert(sizeof(Smem<Cfg<2, 8>>) <= 64 * 1024, "<2,8>: a small workgroup");
 static_assert(sizeof(Smem<Cfg<1, 8>>) <= 64 * 1024, "<1,8>: a small workgroup");
 
@@ -440,9 +464,12 @@ __device__ __forceinline__ void for_each_out(int mt, const f32x4 &acc, F f) {
 
 #ifdef CCSP_STAMPS                        // diagnostic build only (tools/stamps_net.py): s_memtime at the layer boundaries of workgroup 0
 __device__ unsigned long long net_stamps[64];
+__device__ unsigned long long net_stamps2[8][8];          // [wave][point] inside block 4's last 1x1 layer
 #define NET_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) net_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define NET_STAMP2(pt) do { if (blockIdx.x == 0 && lane == 0 && blk == 4) net_stamps2[wave][pt] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define NET_STAMP(i) do { } while (0)
+#define NET_STAMP2(pt) do { } while (0)
 #endif
 
 // REQ (the free-running path's hand-off, ccsp_net_forward_requests): the input is the batch of REQUEST records -- the position, 64 bytes
@@ -478,6 +505,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     // y1, the zero-halo input of the 3x3 layers (only interior cells are ever written again), is cleared in the same phase
     static_assert((PADROWS * LDY) % 4 == 0, "y1 is cleared 16 bytes at a time");
     for (int i = tid * 4; i < PADROWS * LDY; i += NTH * 4) *reinterpret_cast<f32x4 *>(&S.y1[i]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NB < 8 || CCSP_NET_LDS_BIAS_ALL)            // (see bias4 below)
+    for (int i = tid; i < BIAS_N / 4; i += NTH)               // the trunk's biases -> LDS: 308 16-byte pieces (visible behind the input phase's barrier)
+        *reinterpret_cast<f32x4 *>(&S.bias[4 * i]) = *reinterpret_cast<const f32x4 *>(W + LAY.trunk_b + 4 * i);
     const ccsp_request *rq = reinterpret_cast<const ccsp_request *>(planes) + s0;      // (REQ)
     if constexpr (REQ) {
         // C1 in place: the staging area zeroed, then one thread per (position, checker) writes the checker's id + 1 at the cells it
@@ -544,7 +574,14 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     const int kshare = XT ? qr : -1;                             // its share of the last tile's k-range (none in a shape without one)
     const int kh = AS ? qr / MT : 0;                             // AS: its part of the tile's k-range in the 3x3 layers; part 0 computes the tile in the first 1x1
     f32x4 pre[NPREMAX];                                          // the next layer's first weight k-blocks, in flight across barriers
-    auto bias4 = [&](int off) -> f32x4 { return *reinterpret_cast<const f32x4 *>(W + off + 4 * q); };   // this lane's four output channels
+    // this lane's four output channels (idx: BIAS_*).  Through LDS in the shapes whose launch is one workgroup's LATENCY (A/B on one box,
+    // round 5: <4,4> 75.0 -> 73.5 us, <2,8> 46.5 -> 44.7, <1,8> 36.4 -> 34.7); from global memory in <8,8>, where the epilogues that no
+    // longer wait run INTO the partner wave's MFMA stream and the launch of 2048 positions got 1 % longer (118.4 -> 119.5 us)
+    constexpr bool LDS_BIAS = NB < 8 || CCSP_NET_LDS_BIAS_ALL;
+    auto bias4 = [&](int idx) -> f32x4 {
+        if constexpr (LDS_BIAS) return *reinterpret_cast<const f32x4 *>(&S.bias[idx + 4 * q]);
+        else return *reinterpret_cast<const f32x4 *>(W + LAY.trunk_b + idx + 4 * q);
+    };
     auto relu4 = [](const f32x4 &v) -> f32x4 { return f32x4{relu(v[0]), relu(v[1]), relu(v[2]), relu(v[3])}; };
 
     // The trunk's tiles have the same owner in the stem and in every block's last layer (column tile wave & 3, row tiles 6 (wave >> 2)
@@ -571,7 +608,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         auto afrag = [&](int, int kb, int i) -> f32x4 {
             return *reinterpret_cast<const f32x4 *>(&in[sbase[i] + tapoff[kb]]);
         };
-        const f32x4 bv = bias4(LAY.stem_b + nt * 16);
+        const f32x4 bv = bias4(BIAS_STEM + nt * 16);
         auto epi = [&](int mt, const f32x4 &acc, int i) {
             xr[i] = relu4(acc + bv);
             *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
@@ -613,11 +650,12 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     // ---- nine bottleneck residual blocks (model.py:120-145) ------------------------------------------
     f32x4 bq2[AS ? 18 / C::NSH : 1];                             // (AS: this wave's weight k-blocks of the block's 3x3 layer)
     for (int blk = 0; blk < 9; blk++) {
+        const int wo = blk * BLK_STRIDE, bb = BIAS_BLK + blk * BIAS_PER_BLK;     // this block's weights in the blob / biases in LDS
         {   // 1x1 64 -> 32: 2 column tiles x 4 row groups of three tiles + a quarter of tile 12's k-range each
             auto afrag = [&](int mt, int kb, int) -> f32x4 {
                 return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
             };
-            const f32x4 bv = bias4(LAY.l1_b[blk] + nt2 * 16);
+            const f32x4 bv = bias4(bb + BIAS_L1 + nt2 * 16);
             auto epi = [&](int, const f32x4 &acc, int i) {
                 const int at = i == 0 ? prow[0] : (i == 1 ? prow[F32A > 1 ? 1 : 0] : prow[F32A > 2 ? 2 : 0]);
                 if constexpr (C::PADFULL) {
@@ -628,16 +666,16 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             auto epix = [&](const f32x4 &acc) {                                 // the last tile: its real rows only
                 if (l15 < ROWS - (MT - 1) * 16) *reinterpret_cast<f32x4 *>(&S.y1[prowx + nt2 * 16]) = relu4(acc + bv);
             };
-            if constexpr (AS) ksplit_load<18, C::NSH>(wb, LAY.l2_w[blk], nt2, kh, bq2);      // the 3x3 layer's weights: in flight across this layer
+            if constexpr (AS) ksplit_load<18, C::NSH>(wb, (LAY.l2_w[0] + wo), nt2, kh, bq2);      // the 3x3 layer's weights: in flight across this layer
             if constexpr (AS) {
                 // one tile job per (row tile, column tile): the wave with part 0 of the tile's k-range in the 3x3 layer computes it whole
                 // here (a plain chain over k like every other shape's); the 3x3 layer requests its own weights
                 auto epi1 = [&](int, const f32x4 &acc, int) {
                     if (prow_ok[0]) *reinterpret_cast<f32x4 *>(&S.y1[prow[0] + nt2 * 16]) = relu4(acc + bv);
                 };
-                if (kh == 0) gemm_tiles<1, 4, CCSP_NET_SEG_L1>(wb, LAY.l1_w[blk], nt2, mt3, pre, afrag, []() {}, epi1);
+                if (kh == 0) gemm_tiles<1, 4, CCSP_NET_SEG_L1>(wb, (LAY.l1_w[0] + wo), nt2, mt3, pre, afrag, []() {}, epi1);
             } else
-            gemm_tiles_last<F32A, 4, NSPLIT, CCSP_NET_SEG_L1>(wb, LAY.l1_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<18>(wb, LAY.l2_w[blk], nt2, pre); },
+            gemm_tiles_last<F32A, 4, NSPLIT, CCSP_NET_SEG_L1>(wb, (LAY.l1_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<18>(wb, (LAY.l2_w[0] + wo), nt2, pre); },
                                             epi, epix);
         }
         __syncthreads();
@@ -647,7 +685,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 const int tap = kb >> 1;                                        // compile-time after unrolling
                 return *reinterpret_cast<const f32x4 *>(&S.y1[a3[i] + ((tap / 3) * 6 + tap % 3) * LDY + (kb & 1) * 16]);
             };
-            const f32x4 bv = bias4(LAY.l2_b[blk] + nt2 * 16);
+            const f32x4 bv = bias4(bb + BIAS_L2 + nt2 * 16);
             auto epi = [&](int mt, const f32x4 &acc, int i) {
                 *reinterpret_cast<f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + nt2 * 16 + 4 * q]) = relu4(acc + bv);
             };
@@ -657,9 +695,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                     return *reinterpret_cast<const f32x4 *>(&S.y1[a3[0] + ((tap / 3) * 6 + tap % 3) * LDY + (kb & 1) * 16]);
                 };
                 gemm_ksplit<18, C::NSEG, C::NSH>(bq2, kh, afrag_rt, &S.part[mt3 * 2 + nt2][0][0]);
-                prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre);
+                prefetch<2>(wb, (LAY.l3_w[0] + wo), wave & 3, pre);
             } else
-            gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT>(wb, LAY.l2_w[blk], nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<2>(wb, LAY.l3_w[blk], wave & 3, pre); }, epi,
+            gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT>(wb, (LAY.l2_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<2>(wb, (LAY.l3_w[0] + wo), wave & 3, pre); }, epi,
                                                        &S.part[nt2][0][0]);
             NET_STAMP(32 + blk);                             // diagnostic: wave 0 done with its share of the 3x3 layer
 #ifdef CCSP_STAMPS
@@ -676,6 +714,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             // The 3x3 layer's k-split tile (MT - 1) is consumed straight from its partial sums -- no reduction pass, no two extra
             // barriers: part[nt2][c][lane * 4 + j] is, for THIS lane's (row, k-slot), exactly what an activation fragment of
             // k-block nt2 holds, so the waves whose share ends with that tile form ((c0 + c1) + c2) + c3 + bias, ReLU in registers.
+            NET_STAMP2(0);
             const bool has_x = AS || (XT && mt0 + F64 - 1 == MT - 1);       // wave-uniform (AS: EVERY tile of the 3x3 layer arrives as partial sums)
             const int xt = AS ? mt0 : 0;                                    // which of the Smem::part tiles
             f32x4 ax[2];
@@ -685,25 +724,29 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                     f32x4 v = *reinterpret_cast<const f32x4 *>(&S.part[xt * 2 + kb][0][lane * 4]);
 #pragma unroll
                     for (int c = 1; c < C::NSEG; c++) v = v + *reinterpret_cast<const f32x4 *>(&S.part[xt * 2 + kb][c][lane * 4]);
-                    ax[kb] = relu4(v + bias4(LAY.l2_b[blk] + kb * 16));
+                    ax[kb] = relu4(v + bias4(bb + BIAS_L2 + kb * 16));
                 }
             }
             auto afrag = [&](int mt, int kb, int i) -> f32x4 {
                 if (i == F64 - 1 && has_x) return ax[kb];
                 return *reinterpret_cast<const f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + kb * 16 + 4 * q]);
             };
-            const f32x4 bv = bias4(LAY.l3_b[blk] + nt * 16);
+            const f32x4 bv = bias4(bb + BIAS_L3 + nt * 16);
             auto epi = [&](int mt, const f32x4 &acc, int i) {
                 xr[i] = relu4(acc + bv + xr[i]);                                // add([x, block_input]) then ReLU; the input from registers
                 if (C::DUP && half && i == 0) return;                           // ... and stored by the first half only
                 *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
             };
-            gemm_tiles<F64, 2, CCSP_NET_SEG_L3>(wb, LAY.l3_w[blk], nt, mt0, pre, afrag, [&]() {
-                if (blk < 8) prefetch<4>(wb, LAY.l1_w[blk < 8 ? blk + 1 : 8], nt2, pre);
-                else prefetch<4>(wb, LAY.pc_w, 0, pre);
+            NET_STAMP2(1);
+            gemm_tiles<F64, 2, CCSP_NET_SEG_L3>(wb, (LAY.l3_w[0] + wo), nt, mt0, pre, afrag, [&]() {
+                NET_STAMP2(2);
+                // (no branch: the same three loads either way -- the next block's first 1x1 or, behind the last block, the policy conv)
+                prefetch<4>(wb, blk < 8 ? LAY.l1_w[0] + wo + BLK_STRIDE : LAY.pc_w, blk < 8 ? nt2 : 0, pre);
             }, epi);
+            NET_STAMP2(3);
         }
         __syncthreads();
+        NET_STAMP2(4);
         NET_STAMP(4 + 3 * blk);
     }
 
@@ -714,7 +757,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         auto afrag = [&](int mt, int kb, int) -> f32x4 {
             return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
         };
-        const f32x4 bv = bias4(LAY.pc_b);
+        const f32x4 bv = bias4(BIAS_PC);
         auto epi = [&](int mt, const f32x4 &acc, int i) {
             *reinterpret_cast<f32x4 *>(&pc[(mt * 16 + l15) * 16 + 4 * q]) = relu4(acc + bv);
         };
@@ -1009,7 +1052,9 @@ int ccsp_net_forward_requests(const float *packed, const ccsp_request *req, cons
 
 #ifdef CCSP_STAMPS
 int ccsp_debug_net_stamps(unsigned long long *out) {
+    const bool more = out[63] == 0x5eedULL;            // (the caller passes 128 words and says so)
     CCSP_HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(net_stamps), 64 * sizeof(unsigned long long)));
+    if (more) CCSP_HIPCHK(hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(net_stamps2), 64 * sizeof(unsigned long long)));
     return CCSP_OK;
 }
 #endif

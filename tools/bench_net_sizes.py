@@ -13,7 +13,7 @@ packed = m._ensure_packed()
 st = _stream_ptr()
 print('%8s %12s %12s %12s %12s' % ('n', '<8,8> us', '<4,4> us', '<2,8> us', '<1,8> us'))
 import os
-SIZES = (1, 64, 256, 512) if os.environ.get('SMALL_ONLY') else (1, 4, 8, 24, 64, 128, 256, 384, 512, 768, 1024, 1280, 1536, 2048, 4096)
+SIZES = (1, 64, 256, 512) if os.environ.get('SMALL_ONLY') else (1, 256, 512, 1024, 2048) if os.environ.get('FEW') else (1, 4, 8, 24, 64, 128, 256, 384, 512, 768, 1024, 1280, 1536, 2048, 4096)
 for n in SIZES:
     x = torch.rand((n, 343), device='cuda')
     p = torch.empty((n, 294), dtype=torch.float64, device='cuda'); v = torch.empty(n, dtype=torch.float32, device='cuda')

@@ -18,7 +18,8 @@ m = ResidualCNN(backend='hip'); m.load_weights('tests/golden/good_model.h5')
 for _ in range(3):
     m.evaluate_batch(x)
 torch.cuda.synchronize()
-out = (C.c_ulonglong * 64)()
+out = (C.c_ulonglong * 128)()
+out[63] = 0x5eed
 L = _lib.lib()
 L.ccsp_debug_net_stamps.restype = C.c_int
 assert L.ccsp_debug_net_stamps(out) == 0
@@ -45,3 +46,11 @@ print('HW_ID simd per wave:', [(t64[52 + w] >> 4) & 3 for w in range(8)], 'wave 
 
 rt = t64[61] - t64[60]
 print('in-kernel clock of workgroup 0: %d shader ticks / %d realtime ticks (100 MHz) = %.3f GHz' % (t64[31] - t64[0], rt, (t64[31] - t64[0]) / max(rt, 1) * 0.1))
+
+# round 5: inside block 4's last 1x1 layer, per wave: [0] layer start, [1] partial sums of the k-split tile summed (the waves that own it),
+# [2] last MFMA issued, [3] epilogue done (stores issued), [4] past the barrier -- ticks after wave 0's layer start
+s2 = [[int(out[64 + w * 8 + k]) for k in range(5)] for w in range(8)]
+t00 = min(r[0] for r in s2)
+print('last 1x1 of block 4, per wave (ticks after the first wave entered the layer): start / sums / MFMAs issued / epilogue / past barrier')
+for w in range(8):
+    print('  wave %d: %s' % (w, ' '.join('%6d' % (x - t00) for x in s2[w])))
