@@ -7,7 +7,7 @@ env = dict(os.environ)
 if flags:
     from chinesecheckersagent_amd import build as B
     so = os.path.join('chinesecheckersagent_amd', 'libccsp_exp.so')
-    subprocess.check_call(['hipcc'] + B.FLAGS + flags + ['-o', so] + [os.path.join(B.CSRC, f) for f in B.SOURCES])
+    subprocess.check_call(['hipcc'] + B.FLAGS + ['-shared'] + flags + ['-o', so] + [os.path.join(B.CSRC, f) for f in B.SOURCES])
     env['CCSP_LIB'] = os.path.abspath(so)
 for _ in range(2):
     out = subprocess.run([sys.executable, 'bench.py', '--no-extras', '--steps', '48', '--warmup', '5'], env=env, capture_output=True, text=True)

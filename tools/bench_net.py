@@ -6,7 +6,7 @@ import os, subprocess
 if len(sys.argv) > 1:            # extra hipcc flags (e.g. -DCCSP_NET_LDX=72 -DCCSP_NET_LDY=40): an experimental build beside the product's
     from chinesecheckersagent_amd import _lib, build as B
     so = os.path.join('chinesecheckersagent_amd', 'libccsp_exp.so')
-    subprocess.check_call(['hipcc'] + B.FLAGS + sys.argv[1:] + ['-o', so] + [os.path.join(B.CSRC, f) for f in B.SOURCES])
+    subprocess.check_call(['hipcc'] + B.FLAGS + ['-shared'] + sys.argv[1:] + ['-o', so] + [os.path.join(B.CSRC, f) for f in B.SOURCES])
     _lib.LIB_PATH = so
     print('built', so, sys.argv[1:])
 from chinesecheckersagent_amd.model import ResidualCNN

@@ -10,7 +10,7 @@ if len(sys.argv) > 1:            # extra hipcc flags (e.g. -DMG_LINES_STRIDE=36 
     import os, subprocess
     from chinesecheckersagent_amd import build as B
     so = os.path.join('chinesecheckersagent_amd', 'libccsp_exp.so')
-    subprocess.check_call(['hipcc'] + B.FLAGS + sys.argv[1:] + ['-o', so] + [os.path.join(B.CSRC, f) for f in B.SOURCES])
+    subprocess.check_call(['hipcc'] + B.FLAGS + ['-shared'] + sys.argv[1:] + ['-o', so] + [os.path.join(B.CSRC, f) for f in B.SOURCES])
     _lib.LIB_PATH = so
     print('built', so, sys.argv[1:])
 L = _lib.lib()
