@@ -146,7 +146,9 @@ class BatchSelfPlay(object):
         self.n_slots, self.sims = n_slots, sims
         # one simulation step (select kernel -> net forward -> f64 softmax -> expand/backup kernel) is captured
         # once into a hipGraph and replayed `sims` times per ply: the step is launch-bound otherwise
-        self.use_graph = bool(use_graph) and hasattr(self.m1, 'model') and (self.m2 is None or hasattr(self.m2, 'model'))
+        # (a reference-style .predict object evaluates on the HOST: nothing to capture)
+        on_device = lambda m: hasattr(m, 'model') and not isinstance(m, _PredictAdapter)
+        self.use_graph = bool(use_graph) and on_device(self.m1) and (self.m2 is None or on_device(self.m2))
         self._graph = None
         self._root_is_p2 = torch.zeros(n_slots, dtype=torch.bool, device=dev)
         self.free_running = bool(free_running)
