@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-5 steady-state experiments on the free-running path (tools/bench_free.py): limits of a call, tree-wave issue priority (pre-built
 # variants of the library: CCSP_LIB), boundary cadence.   usage (GPU box): bash tools/exp_round5.sh <tag> [what...]
+# (`prio` / `lib:<file>` need the variant built BEFORE the call, in the build container -- the .so travels with the snapshot:
+#  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -shared -DCCSP_ADVANCE_PRIO=1 -o chinesecheckersagent_amd/libccsp_exp_prio1.so chinesecheckersagent_amd/csrc/*.hip)
 tag=$1; shift
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
