@@ -26,6 +26,7 @@
 // with the same mapping (one ds_read_b128 per lane per 16 k).
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 #include "ccsp_common.h"
 
@@ -141,6 +142,49 @@ constexpr int PAD0 = 7, PADPOS = 36;
 //           (half the k-range = two of the four segments each), the 1x1 layers have a job for every wave or every second one -- half the
 //           matrix work per CU of <2, 8>: the shape of the batches whose whole launch is ONE workgroup per CU and nothing but latency
 //           (one game of selfplay(), the arena's and config 5's few dozen slots per GPU: up to 256 positions).
+#ifndef CCSP_NET_SKIP_DEAD_TAPS
+#define CCSP_NET_SKIP_DEAD_TAPS 1
+#endif
+#ifndef CCSP_NET_KB_FENCE
+#define CCSP_NET_KB_FENCE 1
+#endif
+#ifndef CCSP_NET_NE
+#define CCSP_NET_NE 2
+#endif
+// Cell-major rows of <8, 8>: row tile t < 12 holds cells CELL8[2 t], CELL8[2 t + 1] (row 16 t + 8 h + s = position s of cell 2 t + h), tile
+// 12 the 25th cell (+ 8 padding rows).  Row group g = wave >> 1 of the 32-column layers owns tiles 3 g, 3 g + 1 -- two pairs of cells on map
+// edge g (0 top, 1 right, 2 bottom, 3 left: the ring of 16 border cells cut into four runs of four) -- and tile 3 g + 2, a pair of interior cells.
+constexpr unsigned char CELL8[25] = {0, 1, 2, 3, 6, 7,   4, 9, 14, 19, 11, 12,   24, 23, 22, 21, 16, 17,   20, 15, 10, 5, 8, 13,   18};
+constexpr unsigned long long cell8_pack(int from) {
+    unsigned long long v = 0;
+    for (int i = 0; i < 12 && from + i < 25; i++) v |= (unsigned long long)CELL8[from + i] << (5 * i);
+    return v;
+}
+constexpr bool cell8_ok() {
+    bool seen[25] = {};
+    for (int i = 0; i < 25; i++) { if (CELL8[i] > 24 || seen[CELL8[i]]) return false; seen[CELL8[i]] = true; }
+    for (int g = 0; g < 4; g++)
+        for (int i = 0; i < 6; i++) {
+            const int r = CELL8[6 * g + i] / 5, c = CELL8[6 * g + i] % 5;
+            const bool on_edge = g == 0 ? r == 0 : (g == 1 ? c == 4 : (g == 2 ? r == 4 : c == 0));
+            if (i < 4 ? !on_edge : (r == 0 || r == 4 || c == 0 || c == 4)) return false;
+        }
+    return true;
+}
+static_assert(cell8_ok(), "CELL8: a permutation; tiles 3g, 3g+1 on edge g, tile 3g+2 interior");
+__device__ __forceinline__ int cell8(int idx) {                  // CELL8[idx] without a memory access (5-bit fields of three constants)
+    const unsigned long long w = idx < 12 ? cell8_pack(0) : (idx < 24 ? cell8_pack(12) : cell8_pack(24));
+    return (int)((w >> (5 * (idx < 12 ? idx : (idx < 24 ? idx - 12 : 0)))) & 31);
+}
+// the k-blocks (bit kb: tap kb >> 1 = 3 (dr + 1) + (dc + 1)) of a 3x3 layer that read nothing but halo for a tile on edge g
+constexpr int XSEG[4] = {0, 1, 3, 2};                             // row group -> its segment of the shared tile (segments: k-blocks 0-3, 4-8, 9-12, 13-17)
+constexpr unsigned XSEG_PACK = XSEG[0] | XSEG[1] << 4 | XSEG[2] << 8 | XSEG[3] << 12;
+constexpr unsigned EDGE_DEAD[4] = {0x0003Fu /* dr = -1 */, 0x30C30u /* dc = +1 */, 0x3F000u /* dr = +1 */, 0x030C3u /* dc = -1 */};
+// Cell-major zero-halo input of the 3x3 layers: cell (r, c) of position s sits at row (6 r + c + CM_PAD) * 8 + s -- the same shared halo
+// per map row as below, all eight positions of a cell slot together; neighbour (dr, dc) = + (6 dr + dc) * 8 rows.  Only the slots a
+// LIVE tap can reach exist: from (-1, 3) (tap (-1, -1) of cell (0, 4), a right-edge tile) to (5, 1) (tap (+1, +1) of cell (4, 0)).
+constexpr int CM_PAD = 3, CM_SLOTS = 35;
+
 template <int NBv, int NWv>
 struct Cfg {
     static constexpr int NB = NBv, NW = NWv, NTH = NWv * 64, ROWS = NBv * 25, MT = (NBv * 25 + 15) / 16;
@@ -159,7 +203,12 @@ struct Cfg {
     static constexpr int HB = NBv < 4 ? 4 : NBv;                 // positions the heads are laid out for (the 4 x 4 MFMA carries four at a time)
     static constexpr int NSEG = CCSP_NET_SEG_L2;                 // k-segments every output of a 3x3 layer is summed from (gemm_tiles_split): the
                                                                  // SAME in every shape, so that both shapes compute a position with the same bits
-    static constexpr int PADROWS_ = PAD0 + NBv * PADPOS + 1, PADROWS_HEADS = (HB * 400 + LDY - 1) / LDY;
+    // <8, 8> (round 5): rows in CELL-MAJOR order -- a row tile is two cells x eight positions (CELL8), so that a tile whose two cells lie on
+    // the same edge of the 5 x 5 map has three taps of the 3x3 layers that fall off the map for EVERY one of its rows: their k-blocks
+    // multiply nothing but halo zeros and are not issued (EDGE_DEAD; a skipped product is an exact zero: the sums keep their bits).
+    static constexpr bool CELLMAJOR = NBv == 8 && CCSP_NET_SKIP_DEAD_TAPS;
+    static constexpr int NE = CELLMAJOR ? CCSP_NET_NE : 0;                 // a wave's first NE tiles of a 3x3 layer are edge tiles of ONE edge (its row group's)
+    static constexpr int PADROWS_ = CELLMAJOR ? CM_SLOTS * NBv : PAD0 + NBv * PADPOS + 1, PADROWS_HEADS = (HB * 400 + LDY - 1) / LDY;
     static constexpr int PADROWS = PADROWS_ > PADROWS_HEADS ? PADROWS_ : PADROWS_HEADS;   // (the policy conv output of HB positions aliases y1)
     static constexpr int INROWS = NBv * 49 + 56;                 // staged input planes + what padding rows / the zero-weight 10th tap reach
     static constexpr int NTW = (19 + NWv - 1) / NWv;             // policy dense: column tiles per wave
@@ -175,12 +224,14 @@ struct Cfg {
 
 template <typename C>
 struct Smem {
-    float x[C::MT * 16 * LDX > 4 * C::HB * 320 ? C::MT * 16 * LDX : 4 * C::HB * 320];   // 64-channel trunk activations; the policy dense
-                                         // layer's partial sums [4][HB][320] alias it
     float y1[C::PADROWS * LDY];          // 32-channel 1x1 output = 3x3 input, zero halo; the policy conv output aliases it
     static constexpr int Y2A = C::MT * 16 * LDY, Y2B = C::INROWS * LDI, Y2C = 256 + C::HB * (NPOL_PAD + 32);
     static constexpr int Y2N = Y2A > Y2B ? (Y2A > Y2C ? Y2A : Y2C) : (Y2B > Y2C ? Y2B : Y2C);
     float y2[Y2N];                       // 32-channel 3x3 output; the stem's input planes and the logits / value scratch alias it
+    // (y1 and y2 FIRST: a DS instruction's immediate offset is 16 bits -- the cell-major taps of <8,8> reach 16 KB past a lane's base, and
+    // with the 57-KB trunk buffer in front of y1 a third of them no longer fitted: an extra address register per tile, 174 -> 197 VGPRs)
+    float x[C::MT * 16 * LDX > 4 * C::HB * 320 ? C::MT * 16 * LDX : 4 * C::HB * 320];   // 64-channel trunk activations; the policy dense
+                                         // layer's partial sums [4][HB][320] alias it
     float part[2 * C::XTILES][C::NSEG][256];   // partial sums (one per k-segment) of the k-split row tiles of the 3x3 layers: [tile * 2 + column tile]
     float bias[(C::NB < 8 || CCSP_NET_LDS_BIAS_ALL) ? BIAS_N : 4];  // the trunk's biases (see BIAS_*): read by the epilogues through LDS in the small shapes
     static_assert(C::INROWS * LDI <= Y2N, "the staged input planes alias y2");
@@ -191,6 +242,21 @@ static_assert(sizeof(Smem<Cfg<8, 8>>) + 3 * 6900 <= 160 * 1024, "<8,8>: one eval
 static_assert(sizeof(Smem<Cfg<4, 4>>) + 3 * 6900 <= 160 * 1024, "<4,4>: an evaluator workgroup per CU plus three tree-kernel workgroups (two per CU no longer fit: the shape carries batches of at most one workgroup per CU)");
 static_assert(sizeof(Smem<Cfg<2, 8>>) <= 64 * 1024, "<2,8>: a small workgroup");
 static_assert(sizeof(Smem<Cfg<1, 8>>) <= 64 * 1024, "<1,8>: a small workgroup");
+
+// A per-lane LDS base address the compiler cannot see through.  A DS instruction carries a 16-bit immediate offset; clang folds the
+// workgroup-relative offset of a Smem member and the per-tile constant into it where the sum fits -- and where it does not (the trunk
+// buffer behind the first 64 KB: 70272 + tile * 4352), it materialises ONE ADDRESS REGISTER PER TILE in front of the block loop
+// (22 VGPRs, measured with tools/vgpr_liveness.py).  Behind lds_opaque the member's offset sits in the lane's base register and the
+// per-tile constant alone in the immediate.
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+__device__ __forceinline__ lds_float *lds_opaque(float *p) {
+    unsigned a = (unsigned)(size_t)(lds_float *)p;
+    asm volatile("" : "+v"(a));
+    return (lds_float *)(size_t)a;
+}
+__device__ __forceinline__ f32x4 lds_load4(const lds_float *p, int off) { return *reinterpret_cast<const lds_f32x4 *>(p + off); }
+__device__ __forceinline__ void lds_store4(lds_float *p, int off, const f32x4 &v) { *reinterpret_cast<lds_f32x4 *>(p + off) = v; }
 
 // the packed weights as a buffer resource: loads take a scalar byte offset (+ the lane's 16 bytes), no vector address math
 struct WBuf {
@@ -230,6 +296,12 @@ __device__ __forceinline__ void prefetch(const WBuf &wb, int wbase, int nt, f32x
     for (int d = 0; d < Pre<KBN>::N; d++) pre[d] = wb.load(wbase + nt * KBN * 256 + d * 256);
 }
 
+template <int KB, int NSEG>
+__device__ __forceinline__ constexpr int seg_of(int kb) {               // the k-segment k-block kb belongs to
+    int seg = 0;
+    for (int c = 1; c < NSEG; c++) seg += kb >= (KB * c) / NSEG ? 1 : 0;
+    return seg;
+}
 template <int NMT, int KB, int NSEG, typename AFrag, typename Next, typename Epi>
 __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, int mt0, f32x4 (&pre)[NPREMAX], AFrag afrag, Next next, Epi epi) {
     constexpr int NPRE = Pre<KB>::N;
@@ -282,14 +354,22 @@ __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, in
 // EVERY output of these layers -- full tiles too -- is the fixed-order sum ((c0 + c1) + c2) + c3 of NSEG = 4 accumulation chains
 // over four segments of the k-range (in every workgroup shape: the NSH waves that share the last tile take NSEG / NSH segments each), so that a row's arithmetic does not depend on which tile (hence which slot of the
 // batch) it sits in: an evaluation is a function of the position alone, whatever the batch size, the slot or the sharding.
-template <int NMT, int KB, int NSEG, int NSH, typename AFrag, typename Next, typename Epi>
-__device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart, f32x4 (&pre)[NPREMAX],
-                                                 AFrag afrag, Next next, Epi epi, float *part /* [NSEG][256] of this nt */) {
+// NE > 0 (<8, 8>, cell-major rows): the wave's first NE tiles lie on one edge of the map; DEADC has bit kb set for the k-blocks whose
+// tap falls off the map for every row of such a tile -- neither their MFMAs nor their LDS reads exist.  The chains that remain are the
+// ones every other shape forms, minus exact zeros.  STATIC: dead mask and k-share are template constants -- the kernel holds one copy of
+// the layer per row group and picks it with ONE branch per layer; the layer itself is straight-line code, the shared tile's MFMAs
+// interleaved with the others'.  (Round 5, A/B on one box: the same skipping behind scalar branches per k-block -- three of them, taken
+// or not -- gave 7 of the 12 us that the straight-line form gives.)
+template <int NMT, int KB, int NSEG, int NSH, int NE, bool STATIC, unsigned DEADC, int KPARTC, typename AFrag, typename Next, typename Epi>
+__device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart_rt, f32x4 (&pre)[NPREMAX],
+                                                 AFrag afrag, Next next, Epi epi, lds_float *part /* this lane's piece of segment kpart * SPW of this nt: [NSEG][256], + lane * 4 */) {
     constexpr int NPRE = Pre<KB>::N;
     constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;
     constexpr int SPW = NSEG / NSH;                                     // segments of the shared tile that one of its NSH waves computes
     static_assert(NSEG % NSH == 0, "the waves sharing the last tile take whole segments");
-    const int lane = threadIdx.x & 63;
+    static_assert(NE >= 0 && NE < NMT && (NE == 0 || STATIC), "at least one tile without dead taps; dead taps are compile-time");
+    const int kpart = STATIC ? KPARTC : kpart_rt;
+    constexpr unsigned dead = NE > 0 ? DEADC : 0u;
     f32x4 acc[NMT][NSEG], accx[SPW];
 #pragma unroll
     for (int i = 0; i < NMT; i++)
@@ -303,30 +383,47 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
     for (int d = 0; d < NPRE; d++) bq[d] = pre[d];
     f32x4 a[2][NMT + 1];
 #pragma unroll
-    for (int i = 0; i < NMT; i++) a[0][i] = afrag(mt0 + i, 0, i);
-    a[0][NMT] = afrag(xmt, 0, NMT);
+    for (int i = 0; i < NMT; i++)
+        if (i >= NE || !(dead & 1u)) a[0][i] = afrag(mt0 + i, 0, i);
+    if (!STATIC || seg_of<KB, NSEG>(0) / SPW == kpart) a[0][NMT] = afrag(xmt, 0, NMT);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
         int seg = 0;                                                    // the segment k-block kb belongs to (static after unrolling)
 #pragma unroll
         for (int c = 1; c < NSEG; c++) seg += kb >= (KB * c) / NSEG ? 1 : 0;
+        const bool live = !((dead >> kb) & 1u);                         // (static)
         if (kb + 1 < KB) {
 #pragma unroll
-            for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
-            a[(kb + 1) & 1][NMT] = afrag(xmt, kb + 1, NMT);
+            for (int i = 0; i < NMT; i++)
+                if (i >= NE || !((dead >> (kb + 1)) & 1u)) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
+            if (!STATIC || (seg_of<KB, NSEG>(kb + 1)) / SPW == kpart) a[(kb + 1) & 1][NMT] = afrag(xmt, kb + 1, NMT);
         }
         if (kb + PB - 1 < KB && kb + PB - 1 >= NPRE) bq[(kb + PB - 1) % PB] = wb.load(w0 + (kb + PB - 1) * 256);
         const f32x4 b = bq[kb % PB];
+        if constexpr (STATIC) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < 4; j++) {
 #pragma unroll
-            for (int i = 0; i < NMT; i++)
-                acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
-        }
-        if (seg / SPW == kpart) {                                       // wave-uniform: ONE scalar branch per k-block
+                for (int i = 0; i < NMT; i++)
+                    if (i >= NE || live) acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
+                if (seg / SPW == kpart) accx[seg % SPW] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], accx[seg % SPW], 0, 0, 0);
+            }
+#if CCSP_NET_KB_FENCE
+            __builtin_amdgcn_sched_barrier(0);                           // the layer is ONE basic block: without a fence per k-block the max-ILP scheduler
+                                                                        // pulls the loads of many k-blocks to the front (206 VGPRs)
+#endif
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                accx[seg % SPW] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], accx[seg % SPW], 0, 0, 0);
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int i = 0; i < NMT; i++)
+                    acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
+            }
+            if (seg / SPW == kpart) {                                   // wave-uniform: ONE scalar branch per k-block
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    accx[seg % SPW] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], accx[seg % SPW], 0, 0, 0);
+            }
         }
     }
     next();
@@ -339,8 +436,7 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
     }
     if (kpart >= 0) {                                                   // (kpart < 0: a shape without a shared tile)
 #pragma unroll
-        for (int c = 0; c < SPW; c++)
-            *reinterpret_cast<f32x4 *>(&part[(kpart * SPW + c) * 256 + lane * 4]) = accx[c];  // D-fragment order: [segment][lane][reg]
+        for (int c = 0; c < SPW; c++) lds_store4(part, c * 256, accx[c]);   // D-fragment order: [segment][lane][reg]
     }
 }
 
@@ -357,7 +453,7 @@ __device__ __forceinline__ void ksplit_load(const WBuf &wb, int wbase, int nt, i
     for (int j = 0; j < KB / NSH; j++) bq[j] = wb.load(w0 + j * 256);
 }
 template <int KB, int NSEG, int NSH, typename AFrag>
-__device__ __forceinline__ void gemm_ksplit(const f32x4 (&bq)[KB / NSH], int kpart, AFrag afrag, float *part /* [NSEG][256] of this (tile, nt) */) {
+__device__ __forceinline__ void gemm_ksplit(const f32x4 (&bq)[KB / NSH], int kpart, AFrag afrag, lds_float *part /* as in gemm_tiles_split */) {
     constexpr int SPW = NSEG / NSH, KBP = KB / NSH;
     static_assert(NSEG % NSH == 0 && KB % NSH == 0, "whole segments, equal parts");
     constexpr auto seg_lo = [](int c) { return (KB * c) / NSEG; };
@@ -382,7 +478,7 @@ __device__ __forceinline__ void gemm_ksplit(const f32x4 (&bq)[KB / NSH], int kpa
         for (int q = 0; q < 4; q++) accx[seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[q], a[j & 1][q], accx[seg], 0, 0, 0);   // D^T: see tile_out
     }
 #pragma unroll
-    for (int c = 0; c < SPW; c++) *reinterpret_cast<f32x4 *>(&part[(kpart * SPW + c) * 256 + lane * 4]) = accx[c];   // D-fragment order: [segment][lane][reg]
+    for (int c = 0; c < SPW; c++) lds_store4(part, c * 256, accx[c]);   // D-fragment order: [segment][lane][reg]
 }
 
 // The same share-out for the SHORT 32-column layers (the blocks' first 1x1, K = 64): there a reduction pass and its two
@@ -571,9 +667,22 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
 #endif
 
     const int nt2 = wave & 1, qr = wave >> 1, mt3 = AS ? qr % MT : F32 * qr;    // this wave's share of the 32-column layers (see below; AS: its ONE row tile)
-    const int kshare = XT ? qr : -1;                             // its share of the last tile's k-range (none in a shape without one)
+    // its share of the last tile's k-range (none in a shape without one).  Cell-major: the segment most of whose k-blocks are dead for the
+    // wave's edge tiles (XSEG) -- the shared tile's MFMAs fall where the wave has the fewest others.
+    const int kshare = XT ? (C::CELLMAJOR ? (int)((XSEG_PACK >> (4 * qr)) & 3) : qr) : -1;
     const int kh = AS ? qr / MT : 0;                             // AS: its part of the tile's k-range in the 3x3 layers; part 0 computes the tile in the first 1x1
     f32x4 pre[NPREMAX];                                          // the next layer's first weight k-blocks, in flight across barriers
+    // row -> (position s of the workgroup, cell pos = 5 r + c); a padding row gives some valid pair (its results are never read)
+    constexpr bool CM = C::CELLMAJOR;
+    auto row_sp = [&](int row, int &s, int &pos) {
+        if constexpr (CM) { const int t = row >> 4, l = row & 15; pos = cell8(t < 12 ? 2 * t + (l >> 3) : 24); s = l & 7; }
+        else { if (row >= ROWS) row -= 25; s = row / 25; pos = row % 25; }
+    };
+    auto y1_at = [&](int s, int pos, bool top_left) -> int {      // element offset in y1 of the cell (top_left: of its tap (-1, -1))
+        if constexpr (CM) return ((6 * (pos / 5) + pos % 5 + CM_PAD - (top_left ? 7 : 0)) * NB + s) * LDY + 4 * q;
+        else return ((top_left ? 0 : PAD0) + s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;
+    };
+    constexpr int TAPROW = (CM ? NB : 1) * LDY;                    // one cell to the right in y1 (one map row down: 6 of them)
     // this lane's four output channels (idx: BIAS_*).  Through LDS in the shapes whose launch is one workgroup's LATENCY (A/B on one box,
     // round 5: <4,4> 75.0 -> 73.5 us, <2,8> 46.5 -> 44.7, <1,8> 36.4 -> 34.7); from global memory in <8,8>, where the epilogues that no
     // longer wait run INTO the partner wave's MFMA stream and the launch of 2048 positions got 1 % longer (118.4 -> 119.5 us)
@@ -587,6 +696,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     // The trunk's tiles have the same owner in the stem and in every block's last layer (column tile wave & 3, row tiles 6 (wave >> 2)
     // .. + 6): the owner keeps its seven tiles in registers as well, so that the residual add needs no LDS read.
     f32x4 xr[F64];
+    lds_float *const xown = lds_opaque(&S.x[(((wave >> 2) * M64) * 16 + l15) * LDX + (wave & 3) * 16 + 4 * q]);   // this lane's piece of its first tile
     // ---- stem: 3x3 valid, K = 9 taps x 8 -> 5 k-blocks of 2 taps (10th tap = zero weights) -----------
     // A row's nine taps are plain offsets from its top-left input cell (valid convolution); rows past the 200th and the
     // zero-weight 10th tap read staged zeros.  No masks in the loop.
@@ -596,7 +706,8 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
 #pragma unroll
         for (int i = 0; i < F64; i++) {
             const int row = (mt0 + i) * 16 + l15;
-            const int s = row / 25, pos = row % 25;
+            int s = row / 25, pos = row % 25;                  // (rows past the last: staged zeros)
+            if constexpr (CM) row_sp(row, s, pos);
             sbase[i] = (s * 49 + (pos / 5) * 7 + (pos % 5)) * LDI + (q & 1) * 4;
         }
         int tapoff[5];                                         // lane groups q = 0,1 carry tap 2 kb, q = 2,3 tap 2 kb + 1
@@ -609,9 +720,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             return *reinterpret_cast<const f32x4 *>(&in[sbase[i] + tapoff[kb]]);
         };
         const f32x4 bv = bias4(BIAS_STEM + nt * 16);
-        auto epi = [&](int mt, const f32x4 &acc, int i) {
+        auto epi = [&](int, const f32x4 &acc, int i) {
             xr[i] = relu4(acc + bv);
-            *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
+            lds_store4(xown, i * 16 * LDX, xr[i]);
         };
         prefetch<5>(wb, LAY.stem_w, nt, pre);
         gemm_tiles<F64, 5, CCSP_NET_SEG_STEM>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
@@ -621,57 +732,52 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
 
     // 32-column layers: a wave owns row tiles 3 qr .. 3 qr + 2 of column tile nt, and a quarter of tile 12's k-range.
     // Per slot (0-2: the full tiles; 3: tile 12), once for all nine blocks:
-    //   a3[i]     element offset in y1 of the row's TOP-LEFT tap (zero-halo copy): tap (dr, dc) is + (dr*6 + dc) * LDY
-    //   prow[i]   element offset in y1 of the interior cell of this lane's row of tile i (1x1 epilogue -> 3x3 input)
-    int a3[F32A + 1], prow[F32A];
+    //   y1p[i]    in y1, the row's TOP-LEFT tap (zero-halo copy): tap (dr, dc) is + (dr*6 + dc) * TAPROW
+    //   (the interior cell of this lane's row -- 1x1 epilogue -> 3x3 input -- is y1p[i] + CELL0: no second address register per tile)
+    const lds_float *y1p[F32A + 1];                            // (every per-lane LDS base of the block loop: lds_opaque -- see there)
     bool prow_ok[F32A];                                        // (PADFULL shapes: is this lane's row of the tile a real cell?)
 #pragma unroll
     for (int i = 0; i < F32A + 1; i++) {
-        int row = (i < F32A ? mt3 + i : MT - 1) * 16 + l15;
-        if (row >= ROWS) row -= 25;                            // padding rows of the last tile: any valid cell (results never read)
-        const int s = row / 25, pos = row % 25;
-        a3[i] = (s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;              // = cell (r - 1, c - 1): PAD0 - 7 = 0
+        int s, pos;                                            // padding rows of the last tile: any valid cell (results never read)
+        row_sp((i < F32A ? mt3 + i : MT - 1) * 16 + l15, s, pos);
+        y1p[i] = lds_opaque(&S.y1[y1_at(s, pos, true)]);       // = cell (r - 1, c - 1): PAD0 - 7 = 0
+        if (i < F32A) prow_ok[i] = (mt3 + i) * 16 + l15 < ROWS;   // <8,8>, <4,4>: always a real cell
     }
-#pragma unroll
-    for (int i = 0; i < F32A; i++) {
-        int row = (mt3 + i) * 16 + l15;                        // <8,8>, <4,4>: always a real cell
-        prow_ok[i] = row < ROWS;
-        if (row >= ROWS) row -= 25;
-        const int s = row / 25, pos = row % 25;
-        prow[i] = (PAD0 + s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;
-    }
-    int prowx;                                                 // the same for this lane's row of the last tile (real rows: l15 < ROWS - 16 (MT - 1))
-    {
-        const int row = (MT - 1) * 16 + (l15 < ROWS - (MT - 1) * 16 ? l15 : 0);
-        const int s = row / 25, pos = row % 25;
-        prowx = (PAD0 + s * PADPOS + (pos / 5) * 6 + (pos % 5)) * LDY + 4 * q;
-    }
+    constexpr int CELL0 = 7 * TAPROW;                          // the cell itself from its top-left tap: one map row down, one cell to the right
+    const lds_float *const xin = lds_opaque(&S.x[(mt3 * 16 + l15) * LDX + 4 * q]);          // the first 1x1 layer's input rows: this wave's tiles ...
+    const lds_float *const xinx = lds_opaque(&S.x[((MT - 1) * 16 + l15) * LDX + 4 * q]);    // ... and the last tile
+    lds_float *const y2w = lds_opaque(&S.y2[(mt3 * 16 + l15) * LDY + nt2 * 16 + 4 * q]);                 // the 3x3 layer's output: this wave's tiles
+    const lds_float *const y2r = lds_opaque(&S.y2[(((wave >> 2) * M64) * 16 + l15) * LDY + 4 * q]);      // ... as the last 1x1 layer reads it
+    lds_float *const partw = lds_opaque(&S.part[AS ? mt3 * 2 + nt2 : nt2][(AS ? kh : (XT ? kshare : 0)) * (C::NSEG / C::NSH)][lane * 4]);
+    const lds_float *const partr = lds_opaque(&S.part[AS ? ((wave >> 2) * M64) * 2 : 0][0][lane * 4]);
 
     // ---- nine bottleneck residual blocks (model.py:120-145) ------------------------------------------
     f32x4 bq2[AS ? 18 / C::NSH : 1];                             // (AS: this wave's weight k-blocks of the block's 3x3 layer)
     for (int blk = 0; blk < 9; blk++) {
         const int wo = blk * BLK_STRIDE, bb = BIAS_BLK + blk * BIAS_PER_BLK;     // this block's weights in the blob / biases in LDS
+        int n2o = nt2 * 16;                                                      // (opaque per block: the sum y1p[i] + n2o is formed where it is used --
+        asm volatile("" : "+s"(n2o));                                            //  one v_add per tile and layer -- not kept in a register per tile)
         {   // 1x1 64 -> 32: 2 column tiles x 4 row groups of three tiles + a quarter of tile 12's k-range each
-            auto afrag = [&](int mt, int kb, int) -> f32x4 {
-                return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
+            auto afrag = [&](int, int kb, int i) -> f32x4 {                     // (slot i: row tile mt3 + i; slot F32A: the last tile)
+                return i < F32A ? lds_load4(xin, i * 16 * LDX + kb * 16) : lds_load4(xinx, kb * 16);
             };
             const f32x4 bv = bias4(bb + BIAS_L1 + nt2 * 16);
             auto epi = [&](int, const f32x4 &acc, int i) {
-                const int at = i == 0 ? prow[0] : (i == 1 ? prow[F32A > 1 ? 1 : 0] : prow[F32A > 2 ? 2 : 0]);
+                const lds_float *at = i == 0 ? y1p[0] : (i == 1 ? y1p[F32A > 1 ? 1 : 0] : y1p[F32A > 2 ? 2 : 0]);
                 if constexpr (C::PADFULL) {
                     if (!(i == 0 ? prow_ok[0] : (i == 1 ? prow_ok[F32A > 1 ? 1 : 0] : prow_ok[F32A > 2 ? 2 : 0]))) return;
                 }
-                *reinterpret_cast<f32x4 *>(&S.y1[at + nt2 * 16]) = relu4(acc + bv);
+                lds_store4(const_cast<lds_float *>(at), CELL0 + n2o, relu4(acc + bv));
             };
             auto epix = [&](const f32x4 &acc) {                                 // the last tile: its real rows only
-                if (l15 < ROWS - (MT - 1) * 16) *reinterpret_cast<f32x4 *>(&S.y1[prowx + nt2 * 16]) = relu4(acc + bv);
+                if (l15 < ROWS - (MT - 1) * 16) lds_store4(const_cast<lds_float *>(y1p[F32A]), CELL0 + n2o, relu4(acc + bv));
             };
             if constexpr (AS) ksplit_load<18, C::NSH>(wb, (LAY.l2_w[0] + wo), nt2, kh, bq2);      // the 3x3 layer's weights: in flight across this layer
             if constexpr (AS) {
                 // one tile job per (row tile, column tile): the wave with part 0 of the tile's k-range in the 3x3 layer computes it whole
                 // here (a plain chain over k like every other shape's); the 3x3 layer requests its own weights
                 auto epi1 = [&](int, const f32x4 &acc, int) {
-                    if (prow_ok[0]) *reinterpret_cast<f32x4 *>(&S.y1[prow[0] + nt2 * 16]) = relu4(acc + bv);
+                    if (prow_ok[0]) lds_store4(const_cast<lds_float *>(y1p[0]), CELL0 + n2o, relu4(acc + bv));
                 };
                 if (kh == 0) gemm_tiles<1, 4, CCSP_NET_SEG_L1>(wb, (LAY.l1_w[0] + wo), nt2, mt3, pre, afrag, []() {}, epi1);
             } else
@@ -683,22 +789,32 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         {   // 3x3 same 32 -> 32: k-block kb = tap (kb >> 1), channels 16 (kb & 1) ..; the halo supplies the zeros
             auto afrag = [&](int, int kb, int i) -> f32x4 {
                 const int tap = kb >> 1;                                        // compile-time after unrolling
-                return *reinterpret_cast<const f32x4 *>(&S.y1[a3[i] + ((tap / 3) * 6 + tap % 3) * LDY + (kb & 1) * 16]);
+                return lds_load4(y1p[i], ((tap / 3) * 6 + tap % 3) * TAPROW + (kb & 1) * 16);
             };
             const f32x4 bv = bias4(bb + BIAS_L2 + nt2 * 16);
-            auto epi = [&](int mt, const f32x4 &acc, int i) {
-                *reinterpret_cast<f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + nt2 * 16 + 4 * q]) = relu4(acc + bv);
-            };
+            auto epi = [&](int, const f32x4 &acc, int i) { lds_store4(y2w, i * 16 * LDY, relu4(acc + bv)); };
             if constexpr (AS) {
                 auto afrag_rt = [&](int kb) -> f32x4 {                           // (kb: wave-uniform, known at run time)
                     const int tap = kb >> 1;
-                    return *reinterpret_cast<const f32x4 *>(&S.y1[a3[0] + ((tap / 3) * 6 + tap % 3) * LDY + (kb & 1) * 16]);
+                    return lds_load4(y1p[0], ((tap / 3) * 6 + tap % 3) * TAPROW + (kb & 1) * 16);
                 };
-                gemm_ksplit<18, C::NSEG, C::NSH>(bq2, kh, afrag_rt, &S.part[mt3 * 2 + nt2][0][0]);
+                gemm_ksplit<18, C::NSEG, C::NSH>(bq2, kh, afrag_rt, partw);
                 prefetch<2>(wb, (LAY.l3_w[0] + wo), wave & 3, pre);
             } else
-            gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT>(wb, (LAY.l2_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<2>(wb, (LAY.l3_w[0] + wo), wave & 3, pre); }, epi,
-                                                       &S.part[nt2][0][0]);
+            {
+                auto next = [&]() { prefetch<2>(wb, (LAY.l3_w[0] + wo), wave & 3, pre); };
+                if constexpr (CM) {                               // one straight-line copy of the layer per row group (= map edge)
+                    auto run = [&](auto G) {
+                        constexpr int g = decltype(G)::value;
+                        gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT, C::NE, true, EDGE_DEAD[g], XSEG[g]>(wb, (LAY.l2_w[0] + wo), nt2, mt3, MT - 1, 0, pre, afrag, next, epi, partw);
+                    };
+                    if (qr == 0) run(std::integral_constant<int, 0>{});
+                    else if (qr == 1) run(std::integral_constant<int, 1>{});
+                    else if (qr == 2) run(std::integral_constant<int, 2>{});
+                    else run(std::integral_constant<int, 3>{});
+                } else
+                    gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT, 0, false, 0u, 0>(wb, (LAY.l2_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, next, epi, partw);
+            }
             NET_STAMP(32 + blk);                             // diagnostic: wave 0 done with its share of the 3x3 layer
 #ifdef CCSP_STAMPS
             if (blockIdx.x == 0 && lane == 0 && blk == 4) {
@@ -721,21 +837,21 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             if (has_x) {
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++) {
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(&S.part[xt * 2 + kb][0][lane * 4]);
+                    f32x4 v = lds_load4(partr, kb * C::NSEG * 256);
 #pragma unroll
-                    for (int c = 1; c < C::NSEG; c++) v = v + *reinterpret_cast<const f32x4 *>(&S.part[xt * 2 + kb][c][lane * 4]);
+                    for (int c = 1; c < C::NSEG; c++) v = v + lds_load4(partr, (kb * C::NSEG + c) * 256);
                     ax[kb] = relu4(v + bias4(bb + BIAS_L2 + kb * 16));
                 }
             }
             auto afrag = [&](int mt, int kb, int i) -> f32x4 {
                 if (i == F64 - 1 && has_x) return ax[kb];
-                return *reinterpret_cast<const f32x4 *>(&S.y2[(mt * 16 + l15) * LDY + kb * 16 + 4 * q]);
+                return lds_load4(y2r, i * 16 * LDY + kb * 16);
             };
             const f32x4 bv = bias4(bb + BIAS_L3 + nt * 16);
             auto epi = [&](int mt, const f32x4 &acc, int i) {
                 xr[i] = relu4(acc + bv + xr[i]);                                // add([x, block_input]) then ReLU; the input from registers
                 if (C::DUP && half && i == 0) return;                           // ... and stored by the first half only
-                *reinterpret_cast<f32x4 *>(&S.x[(mt * 16 + l15) * LDX + nt * 16 + 4 * q]) = xr[i];
+                lds_store4(xown, i * 16 * LDX, xr[i]);
             };
             NET_STAMP2(1);
             gemm_tiles<F64, 2, CCSP_NET_SEG_L3>(wb, (LAY.l3_w[0] + wo), nt, mt0, pre, afrag, [&]() {
@@ -754,12 +870,19 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     float *pc = S.y1;                                    // [208][16] floats; only rows < 200 are read
     {
         const int mt0 = 2 * wave < MT - 2 ? 2 * wave : MT - 2;   // two tiles per wave; the last waves share the last two (plain stores)
-        auto afrag = [&](int mt, int kb, int) -> f32x4 {
-            return *reinterpret_cast<const f32x4 *>(&S.x[(mt * 16 + l15) * LDX + kb * 16 + 4 * q]);
-        };
+        const lds_float *const xpc = lds_opaque(&S.x[(mt0 * 16 + l15) * LDX + 4 * q]);
+        auto afrag = [&](int, int kb, int i) -> f32x4 { return lds_load4(xpc, i * 16 * LDX + kb * 16); };
         const f32x4 bv = bias4(BIAS_PC);
-        auto epi = [&](int mt, const f32x4 &acc, int i) {
-            *reinterpret_cast<f32x4 *>(&pc[(mt * 16 + l15) * 16 + 4 * q]) = relu4(acc + bv);
+        int pcat[2];                                         // [position][cell][16]; padding rows go behind the 200th
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int row = (mt0 + i) * 16 + l15;
+            int s, pos;
+            row_sp(row, s, pos);
+            pcat[i] = (CM ? (row < ROWS ? s * 25 + pos : row) : row) * 16 + 4 * q;
+        }
+        auto epi = [&](int, const f32x4 &acc, int i) {
+            *reinterpret_cast<f32x4 *>(&pc[pcat[i]]) = relu4(acc + bv);
         };
         gemm_tiles<2, 4, CCSP_NET_SEG_PC>(wb, LAY.pc_w, 0, mt0, pre, afrag, []() {}, epi);
     }
@@ -772,7 +895,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         const float *xr = &S.x[tid * LDX];
 #pragma unroll 8
         for (int k = 0; k < 64; k++) acc += xr[k] * wv[k];
-        vc[tid] = acc > 0.f ? acc : 0.f;
+        int s, pos;
+        row_sp(tid, s, pos);
+        vc[CM ? s * 25 + pos : tid] = acc > 0.f ? acc : 0.f;
     }
     __syncthreads();
     NET_STAMP(29);
