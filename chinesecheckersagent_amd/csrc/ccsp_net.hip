@@ -148,40 +148,48 @@ constexpr int PAD0 = 7, PADPOS = 36;
 #ifndef CCSP_NET_KB_FENCE
 #define CCSP_NET_KB_FENCE 1
 #endif
-#ifndef CCSP_NET_NE
-#define CCSP_NET_NE 2
+#ifndef CCSP_NET_CM4
+#define CCSP_NET_CM4 1
 #endif
-// Cell-major rows of <8, 8>: row tile t < 12 holds cells CELL8[2 t], CELL8[2 t + 1] (row 16 t + 8 h + s = position s of cell 2 t + h), tile
-// 12 the 25th cell (+ 8 padding rows).  Row group g = wave >> 1 of the 32-column layers owns tiles 3 g, 3 g + 1 -- two pairs of cells on map
-// edge g (0 top, 1 right, 2 bottom, 3 left: the ring of 16 border cells cut into four runs of four) -- and tile 3 g + 2, a pair of interior cells.
+// Cell-major rows (<8, 8> and <4, 4>): a row tile holds 16 / NB cells x NB positions (row 16 t + NB h + s = position s of the tile's h-th
+// cell), the last tile the 25th cell (+ padding rows).  The ring of 16 border cells is cut into four runs of four, one per map edge
+// (0 top, 1 right, 2 bottom, 3 left): an EDGE TILE is cells of one run -- <8, 8>: two tiles per edge, <4, 4>: one.
+//   <8, 8>: row group g = wave >> 1 of the 32-column layers owns tiles 3 g, 3 g + 1 (edge g) and 3 g + 2 (a pair of interior cells);
+//   <4, 4>: row group g owns tiles 3 g, 3 g + 1 (edges 2 g and 2 g + 1) and 3 g + 2 (four interior cells).
 constexpr unsigned char CELL8[25] = {0, 1, 2, 3, 6, 7,   4, 9, 14, 19, 11, 12,   24, 23, 22, 21, 16, 17,   20, 15, 10, 5, 8, 13,   18};
-constexpr unsigned long long cell8_pack(int from) {
+constexpr unsigned char CELL4[25] = {0, 1, 2, 3,  4, 9, 14, 19,  6, 7, 8, 11,   24, 23, 22, 21,  20, 15, 10, 5,  12, 13, 16, 17,   18};
+constexpr int on_edge(int cell, int e) { return e == 0 ? cell / 5 == 0 : (e == 1 ? cell % 5 == 4 : (e == 2 ? cell / 5 == 4 : cell % 5 == 0)); }
+constexpr bool interior(int cell) { return !on_edge(cell, 0) && !on_edge(cell, 1) && !on_edge(cell, 2) && !on_edge(cell, 3); }
+constexpr bool cells_ok() {
+    bool seen8[25] = {}, seen4[25] = {};
+    for (int i = 0; i < 25; i++) {
+        if (CELL8[i] > 24 || seen8[CELL8[i]] || CELL4[i] > 24 || seen4[CELL4[i]]) return false;
+        seen8[CELL8[i]] = true; seen4[CELL4[i]] = true;
+    }
+    for (int g = 0; g < 4; g++)
+        for (int i = 0; i < 6; i++)
+            if (i < 4 ? !on_edge(CELL8[6 * g + i], g) : !interior(CELL8[6 * g + i])) return false;
+    for (int g = 0; g < 2; g++)
+        for (int i = 0; i < 12; i++)
+            if (i < 8 ? !on_edge(CELL4[12 * g + i], 2 * g + i / 4) : !interior(CELL4[12 * g + i])) return false;
+    return interior(CELL8[24]) && interior(CELL4[24]);
+}
+static_assert(cells_ok(), "CELL8 / CELL4: permutations; the edge tiles on their edges, the other tiles interior");
+template <int NB>
+constexpr unsigned long long cell_pack(int from) {
     unsigned long long v = 0;
-    for (int i = 0; i < 12 && from + i < 25; i++) v |= (unsigned long long)CELL8[from + i] << (5 * i);
+    for (int i = 0; i < 12 && from + i < 25; i++) v |= (unsigned long long)(NB == 8 ? CELL8 : CELL4)[from + i] << (5 * i);
     return v;
 }
-constexpr bool cell8_ok() {
-    bool seen[25] = {};
-    for (int i = 0; i < 25; i++) { if (CELL8[i] > 24 || seen[CELL8[i]]) return false; seen[CELL8[i]] = true; }
-    for (int g = 0; g < 4; g++)
-        for (int i = 0; i < 6; i++) {
-            const int r = CELL8[6 * g + i] / 5, c = CELL8[6 * g + i] % 5;
-            const bool on_edge = g == 0 ? r == 0 : (g == 1 ? c == 4 : (g == 2 ? r == 4 : c == 0));
-            if (i < 4 ? !on_edge : (r == 0 || r == 4 || c == 0 || c == 4)) return false;
-        }
-    return true;
-}
-static_assert(cell8_ok(), "CELL8: a permutation; tiles 3g, 3g+1 on edge g, tile 3g+2 interior");
-__device__ __forceinline__ int cell8(int idx) {                  // CELL8[idx] without a memory access (5-bit fields of three constants)
-    const unsigned long long w = idx < 12 ? cell8_pack(0) : (idx < 24 ? cell8_pack(12) : cell8_pack(24));
+template <int NB>
+__device__ __forceinline__ int cell_of(int idx) {                // CELLn[idx] without a memory access (5-bit fields of three constants)
+    const unsigned long long w = idx < 12 ? cell_pack<NB>(0) : (idx < 24 ? cell_pack<NB>(12) : cell_pack<NB>(24));
     return (int)((w >> (5 * (idx < 12 ? idx : (idx < 24 ? idx - 12 : 0)))) & 31);
 }
 // the k-blocks (bit kb: tap kb >> 1 = 3 (dr + 1) + (dc + 1)) of a 3x3 layer that read nothing but halo for a tile on edge g
-constexpr int XSEG[4] = {0, 1, 3, 2};                             // row group -> its segment of the shared tile (segments: k-blocks 0-3, 4-8, 9-12, 13-17)
-constexpr unsigned XSEG_PACK = XSEG[0] | XSEG[1] << 4 | XSEG[2] << 8 | XSEG[3] << 12;
 constexpr unsigned EDGE_DEAD[4] = {0x0003Fu /* dr = -1 */, 0x30C30u /* dc = +1 */, 0x3F000u /* dr = +1 */, 0x030C3u /* dc = -1 */};
-// Cell-major zero-halo input of the 3x3 layers: cell (r, c) of position s sits at row (6 r + c + CM_PAD) * 8 + s -- the same shared halo
-// per map row as below, all eight positions of a cell slot together; neighbour (dr, dc) = + (6 dr + dc) * 8 rows.  Only the slots a
+// Cell-major zero-halo input of the 3x3 layers: cell (r, c) of position s sits at row (6 r + c + CM_PAD) * NB + s -- the same shared halo
+// per map row as below, all NB positions of a cell slot together; neighbour (dr, dc) = + (6 dr + dc) * NB rows.  Only the slots a
 // LIVE tap can reach exist: from (-1, 3) (tap (-1, -1) of cell (0, 4), a right-edge tile) to (5, 1) (tap (+1, +1) of cell (4, 0)).
 constexpr int CM_PAD = 3, CM_SLOTS = 35;
 
@@ -206,8 +214,12 @@ struct Cfg {
     // <8, 8> (round 5): rows in CELL-MAJOR order -- a row tile is two cells x eight positions (CELL8), so that a tile whose two cells lie on
     // the same edge of the 5 x 5 map has three taps of the 3x3 layers that fall off the map for EVERY one of its rows: their k-blocks
     // multiply nothing but halo zeros and are not issued (EDGE_DEAD; a skipped product is an exact zero: the sums keep their bits).
-    static constexpr bool CELLMAJOR = NBv == 8 && CCSP_NET_SKIP_DEAD_TAPS;
-    static constexpr int NE = CELLMAJOR ? CCSP_NET_NE : 0;                 // a wave's first NE tiles of a 3x3 layer are edge tiles of ONE edge (its row group's)
+    static constexpr bool CELLMAJOR = (NBv == 8 || (NBv == 4 && CCSP_NET_CM4)) && CCSP_NET_SKIP_DEAD_TAPS;
+    static constexpr int NE = CELLMAJOR ? 2 : 0;                 // a wave's first NE tiles of a 3x3 layer are edge tiles
+    static constexpr unsigned dead_of(int g, int slot) { return NBv == 8 ? EDGE_DEAD[g] : EDGE_DEAD[2 * g + slot]; }   // row group g, tile slot 0 / 1
+    // row group -> its share of the shared tile's k-range.  <8, 8> (one segment each; segments: k-blocks 0-3, 4-8, 9-12, 13-17): the
+    // segment most of whose k-blocks are dead for the group's edge -- the shared tile's MFMAs fall where the wave has the fewest others
+    static constexpr int xseg_of(int g) { return NBv == 8 ? (g == 2 ? 3 : (g == 3 ? 2 : g)) : g; }
     static constexpr int PADROWS_ = CELLMAJOR ? CM_SLOTS * NBv : PAD0 + NBv * PADPOS + 1, PADROWS_HEADS = (HB * 400 + LDY - 1) / LDY;
     static constexpr int PADROWS = PADROWS_ > PADROWS_HEADS ? PADROWS_ : PADROWS_HEADS;   // (the policy conv output of HB positions aliases y1)
     static constexpr int INROWS = NBv * 49 + 56;                 // staged input planes + what padding rows / the zero-weight 10th tap reach
@@ -354,22 +366,22 @@ __device__ __forceinline__ void gemm_tiles(const WBuf &wb, int wbase, int nt, in
 // EVERY output of these layers -- full tiles too -- is the fixed-order sum ((c0 + c1) + c2) + c3 of NSEG = 4 accumulation chains
 // over four segments of the k-range (in every workgroup shape: the NSH waves that share the last tile take NSEG / NSH segments each), so that a row's arithmetic does not depend on which tile (hence which slot of the
 // batch) it sits in: an evaluation is a function of the position alone, whatever the batch size, the slot or the sharding.
-// NE > 0 (<8, 8>, cell-major rows): the wave's first NE tiles lie on one edge of the map; DEADC has bit kb set for the k-blocks whose
+// NE > 0 (<8, 8>, cell-major rows): the wave's first NE tiles lie on one edge of the map; DEAD0 / DEAD1 (tile slot 0 / 1) have bit kb set for the k-blocks whose
 // tap falls off the map for every row of such a tile -- neither their MFMAs nor their LDS reads exist.  The chains that remain are the
 // ones every other shape forms, minus exact zeros.  STATIC: dead mask and k-share are template constants -- the kernel holds one copy of
 // the layer per row group and picks it with ONE branch per layer; the layer itself is straight-line code, the shared tile's MFMAs
 // interleaved with the others'.  (Round 5, A/B on one box: the same skipping behind scalar branches per k-block -- three of them, taken
 // or not -- gave 7 of the 12 us that the straight-line form gives.)
-template <int NMT, int KB, int NSEG, int NSH, int NE, bool STATIC, unsigned DEADC, int KPARTC, typename AFrag, typename Next, typename Epi>
+template <int NMT, int KB, int NSEG, int NSH, int NE, bool STATIC, unsigned DEAD0, unsigned DEAD1, int KPARTC, typename AFrag, typename Next, typename Epi>
 __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart_rt, f32x4 (&pre)[NPREMAX],
                                                  AFrag afrag, Next next, Epi epi, lds_float *part /* this lane's piece of segment kpart * SPW of this nt: [NSEG][256], + lane * 4 */) {
     constexpr int NPRE = Pre<KB>::N;
     constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;
     constexpr int SPW = NSEG / NSH;                                     // segments of the shared tile that one of its NSH waves computes
     static_assert(NSEG % NSH == 0, "the waves sharing the last tile take whole segments");
-    static_assert(NE >= 0 && NE < NMT && (NE == 0 || STATIC), "at least one tile without dead taps; dead taps are compile-time");
+    static_assert(NE >= 0 && NE <= 2 && NE < NMT && (NE == 0 || STATIC), "at least one tile without dead taps; dead taps are compile-time");
     const int kpart = STATIC ? KPARTC : kpart_rt;
-    constexpr unsigned dead = NE > 0 ? DEADC : 0u;
+    constexpr auto is_live = [](int i, int kb) { return i >= NE || !(((i == 0 ? DEAD0 : DEAD1) >> kb) & 1u); };     // tile slot i in k-block kb
     f32x4 acc[NMT][NSEG], accx[SPW];
 #pragma unroll
     for (int i = 0; i < NMT; i++)
@@ -384,18 +396,17 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
     f32x4 a[2][NMT + 1];
 #pragma unroll
     for (int i = 0; i < NMT; i++)
-        if (i >= NE || !(dead & 1u)) a[0][i] = afrag(mt0 + i, 0, i);
+        if (is_live(i, 0)) a[0][i] = afrag(mt0 + i, 0, i);
     if (!STATIC || seg_of<KB, NSEG>(0) / SPW == kpart) a[0][NMT] = afrag(xmt, 0, NMT);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
         int seg = 0;                                                    // the segment k-block kb belongs to (static after unrolling)
 #pragma unroll
         for (int c = 1; c < NSEG; c++) seg += kb >= (KB * c) / NSEG ? 1 : 0;
-        const bool live = !((dead >> kb) & 1u);                         // (static)
         if (kb + 1 < KB) {
 #pragma unroll
             for (int i = 0; i < NMT; i++)
-                if (i >= NE || !((dead >> (kb + 1)) & 1u)) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
+                if (is_live(i, kb + 1)) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
             if (!STATIC || (seg_of<KB, NSEG>(kb + 1)) / SPW == kpart) a[(kb + 1) & 1][NMT] = afrag(xmt, kb + 1, NMT);
         }
         if (kb + PB - 1 < KB && kb + PB - 1 >= NPRE) bq[(kb + PB - 1) % PB] = wb.load(w0 + (kb + PB - 1) * 256);
@@ -405,7 +416,7 @@ __device__ __forceinline__ void gemm_tiles_split(const WBuf &wb, int wbase, int 
             for (int j = 0; j < 4; j++) {
 #pragma unroll
                 for (int i = 0; i < NMT; i++)
-                    if (i >= NE || live) acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
+                    if (is_live(i, kb)) acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
                 if (seg / SPW == kpart) accx[seg % SPW] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], accx[seg % SPW], 0, 0, 0);
             }
 #if CCSP_NET_KB_FENCE
@@ -669,13 +680,13 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     const int nt2 = wave & 1, qr = wave >> 1, mt3 = AS ? qr % MT : F32 * qr;    // this wave's share of the 32-column layers (see below; AS: its ONE row tile)
     // its share of the last tile's k-range (none in a shape without one).  Cell-major: the segment most of whose k-blocks are dead for the
     // wave's edge tiles (XSEG) -- the shared tile's MFMAs fall where the wave has the fewest others.
-    const int kshare = XT ? (C::CELLMAJOR ? (int)((XSEG_PACK >> (4 * qr)) & 3) : qr) : -1;
+    const int kshare = XT ? (C::CELLMAJOR ? (qr == 0 ? C::xseg_of(0) : (qr == 1 ? C::xseg_of(1) : (qr == 2 ? C::xseg_of(2) : C::xseg_of(3)))) : qr) : -1;
     const int kh = AS ? qr / MT : 0;                             // AS: its part of the tile's k-range in the 3x3 layers; part 0 computes the tile in the first 1x1
     f32x4 pre[NPREMAX];                                          // the next layer's first weight k-blocks, in flight across barriers
     // row -> (position s of the workgroup, cell pos = 5 r + c); a padding row gives some valid pair (its results are never read)
     constexpr bool CM = C::CELLMAJOR;
     auto row_sp = [&](int row, int &s, int &pos) {
-        if constexpr (CM) { const int t = row >> 4, l = row & 15; pos = cell8(t < 12 ? 2 * t + (l >> 3) : 24); s = l & 7; }
+        if constexpr (CM) { const int t = row >> 4, l = row & 15; pos = cell_of<NB>(t < MT - 1 ? t * (16 / NB) + l / NB : 24); s = l % NB; }
         else { if (row >= ROWS) row -= 25; s = row / 25; pos = row % 25; }
     };
     auto y1_at = [&](int s, int pos, bool top_left) -> int {      // element offset in y1 of the cell (top_left: of its tap (-1, -1))
@@ -806,14 +817,14 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 if constexpr (CM) {                               // one straight-line copy of the layer per row group (= map edge)
                     auto run = [&](auto G) {
                         constexpr int g = decltype(G)::value;
-                        gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT, C::NE, true, EDGE_DEAD[g], XSEG[g]>(wb, (LAY.l2_w[0] + wo), nt2, mt3, MT - 1, 0, pre, afrag, next, epi, partw);
+                        gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT, C::NE, true, C::dead_of(g, 0), C::dead_of(g, 1), C::xseg_of(g)>(wb, (LAY.l2_w[0] + wo), nt2, mt3, MT - 1, 0, pre, afrag, next, epi, partw);
                     };
                     if (qr == 0) run(std::integral_constant<int, 0>{});
-                    else if (qr == 1) run(std::integral_constant<int, 1>{});
-                    else if (qr == 2) run(std::integral_constant<int, 2>{});
-                    else run(std::integral_constant<int, 3>{});
+                    else if (NSPLIT == 2 || qr == 1) run(std::integral_constant<int, 1>{});
+                    else if (qr == 2) run(std::integral_constant<int, NSPLIT == 2 ? 1 : 2>{});
+                    else run(std::integral_constant<int, NSPLIT == 2 ? 1 : 3>{});
                 } else
-                    gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT, 0, false, 0u, 0>(wb, (LAY.l2_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, next, epi, partw);
+                    gemm_tiles_split<F32A, 18, C::NSEG, NSPLIT, 0, false, 0u, 0u, 0>(wb, (LAY.l2_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, next, epi, partw);
             }
             NET_STAMP(32 + blk);                             // diagnostic: wave 0 done with its share of the 3x3 layer
 #ifdef CCSP_STAMPS
