@@ -134,7 +134,7 @@ constexpr int PAD0 = 7, PADPOS = 36;
 //           do not fill the GPU (up to 1024 positions), whose launch is as long as one workgroup;
 //   <2, 8>: 50 rows = 4 tiles (22 % padding), 51 KB, eight waves with ONE tile job each in the 32-column layers: the shape of
 //           the smallest batches (one game of selfplay(), the arena's few games per GPU), where only latency counts.
-// Tile shares: 64-column layers -- wave & 3 = column tile, F64 row tiles from M64 * (wave >> 2) (in <8, 8> the two halves both
+// Tile shares: 64-column layers -- wave & 3 = column tile, F64 (second half: F64B) row tiles from M64 * (wave >> 2) (until round 5 the two halves of <8, 8> both
 // compute tile 6); 32-column layers -- wave & 1 = column tile, F32 row tiles from F32 * (wave >> 1) plus, where the tiles do not
 // divide (XT), a 1/NSPLIT share of the k-range of the last tile MT - 1.  Every shape forms every output by the same chains in the
 // same order: a position's result does not depend on the shape.
@@ -204,9 +204,10 @@ struct Cfg {
     static constexpr int F32A = F32 > 0 ? F32 : 1;               // (array extents: at least one slot)
     static constexpr int XT = ALLSPLIT ? 0 : MT - F32 * NSPLIT;  // 1: a last row tile shared by the NSPLIT waves of a column tile; 0: none
     static constexpr int NH = NWv / 4;                           // row halves of the 64-column layers
-    static constexpr int F64 = (MT + NH - 1) / NH;               // row tiles per wave in the 64-column layers (7, 7, 2)
-    static constexpr int M64 = MT - F64;                         // first tile of the second half (6: tile 6 twice; 0; 2)
-    static constexpr bool DUP = NH == 2 && 2 * F64 > MT;         // the halves overlap in one tile: stored by the first half only
+    static constexpr int F64 = (MT + NH - 1) / NH;               // row tiles per wave of the first half in the 64-column layers (7, 7, 2, 1)
+    static constexpr int M64 = NH == 2 ? F64 : 0;                // first tile of the second half
+    static constexpr int F64B = NH == 2 ? MT - F64 : F64;        // its row tiles per wave (<8, 8>: 6 -- the two waves of a SIMD, one of each half, have
+                                                                 // 13 tile jobs between them; until round 5 both halves computed tile 6: 14)
     static constexpr bool PADFULL = F32 * NSPLIT * 16 > ROWS;    // the "full" tiles of the 32-column layers hold padding rows
     static constexpr int HB = NBv < 4 ? 4 : NBv;                 // positions the heads are laid out for (the 4 x 4 MFMA carries four at a time)
     static constexpr int NSEG = CCSP_NET_SEG_L2;                 // k-segments every output of a 3x3 layer is summed from (gemm_tiles_split): the
@@ -231,7 +232,7 @@ struct Cfg {
     // what L2 delivers (one group ahead is enough; more was slower); the small shapes' few workgroups wait for L2 LATENCY instead.
     static constexpr int PDG = NBv <= 2 ? CCSP_NET_PDG_SMALL : CCSP_NET_PDG;
     static_assert((XT == 0 || XT == 1) && (F32 >= 1 || ALLSPLIT) && F32 <= 3 && F64 <= 7 && MT <= 13 && (NWv == 4 || NWv == 8), "tile shares");
-    static_assert(!ALLSPLIT || (NSPLIT % MT == 0 && NSEG % NSH == 0 && F64 == 1 && M64 + 1 == MT), "<1, 8>: two waves per 3x3 tile job, one 64-column job per wave");
+    static_assert(!ALLSPLIT || (NSPLIT % MT == 0 && NSEG % NSH == 0 && F64 == 1 && F64B == 1 && M64 + 1 == MT), "<1, 8>: two waves per 3x3 tile job, one 64-column job per wave");
 };
 
 template <typename C>
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                                                              float *__restrict__ logits_out, double *__restrict__ p_out,
                                                              float *__restrict__ v_out, const uint16_t *__restrict__ moves) {
     constexpr int NB = C::NB, NTH = C::NTH, ROWS = C::ROWS, MT = C::MT, NSPLIT = C::NSPLIT, PADROWS = C::PADROWS, INROWS = C::INROWS,
-                  NW = C::NW, F32 = C::F32, F32A = C::F32A, F64 = C::F64, M64 = C::M64, XT = C::XT, HB = C::HB;
+                  NW = C::NW, F32 = C::F32, F32A = C::F32A, F64 = C::F64, F64B = C::F64B, M64 = C::M64, XT = C::XT, HB = C::HB;
     constexpr bool AS = C::ALLSPLIT;                              // <1, 8>: every 3x3 tile job is shared by NSH waves (see Cfg)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem<C> &S = *reinterpret_cast<Smem<C> *>(smem_raw);
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
     // A row's nine taps are plain offsets from its top-left input cell (valid convolution); rows past the 200th and the
     // zero-weight 10th tap read staged zeros.  No masks in the loop.
     {
-        const int nt = wave & 3, mt0 = (wave >> 2) * M64;      // 4 column tiles x row halves: <8,8> tiles 0-6 and 6-12 (tile 6 twice: a plain store)
+        const int nt = wave & 3, mt0 = (wave >> 2) * M64;      // 4 column tiles x row halves: <8,8> tiles 0-6 and 7-12
         int sbase[F64];
 #pragma unroll
         for (int i = 0; i < F64; i++) {
@@ -736,7 +737,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             lds_store4(xown, i * 16 * LDX, xr[i]);
         };
         prefetch<5>(wb, LAY.stem_w, nt, pre);
-        gemm_tiles<F64, 5, CCSP_NET_SEG_STEM>(wb, LAY.stem_w, nt, mt0, pre, afrag, [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); }, epi);
+        auto next = [&]() { prefetch<4>(wb, LAY.l1_w[0], nt2, pre); };
+        if (F64B == F64 || (wave >> 2) == 0) gemm_tiles<F64, 5, CCSP_NET_SEG_STEM>(wb, LAY.stem_w, nt, mt0, pre, afrag, next, epi);
+        else gemm_tiles<F64B, 5, CCSP_NET_SEG_STEM>(wb, LAY.stem_w, nt, mt0, pre, afrag, next, epi);
     }
     __syncthreads();
     NET_STAMP(1);
@@ -837,12 +840,13 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
         __syncthreads();
         NET_STAMP(3 + 3 * blk);
         {   // 1x1 32 -> 64 + residual: 4 column tiles x 2 row halves
-            const int nt = wave & 3, half = wave >> 2, mt0 = half * M64;     // <8,8>: tiles 0-6 and 6-12: tile 6 is computed by both halves ...
+            const int nt = wave & 3, half = wave >> 2, mt0 = half * M64;     // <8,8>: tiles 0-6 and 7-12
             // The 3x3 layer's k-split tile (MT - 1) is consumed straight from its partial sums -- no reduction pass, no two extra
             // barriers: part[nt2][c][lane * 4 + j] is, for THIS lane's (row, k-slot), exactly what an activation fragment of
             // k-block nt2 holds, so the waves whose share ends with that tile form ((c0 + c1) + c2) + c3 + bias, ReLU in registers.
             NET_STAMP2(0);
-            const bool has_x = AS || (XT && mt0 + F64 - 1 == MT - 1);       // wave-uniform (AS: EVERY tile of the 3x3 layer arrives as partial sums)
+            const bool has_x = AS || (XT && half == C::NH - 1);             // wave-uniform (AS: EVERY tile of the 3x3 layer arrives as partial sums)
+            constexpr int XSLOT = F64B - 1;                                 // the tile slot of the last tile in the wave that has it
             const int xt = AS ? mt0 : 0;                                    // which of the Smem::part tiles
             f32x4 ax[2];
             if (has_x) {
@@ -855,21 +859,22 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 }
             }
             auto afrag = [&](int mt, int kb, int i) -> f32x4 {
-                if (i == F64 - 1 && has_x) return ax[kb];
+                if (i == XSLOT && has_x) return ax[kb];
                 return lds_load4(y2r, i * 16 * LDY + kb * 16);
             };
             const f32x4 bv = bias4(bb + BIAS_L3 + nt * 16);
             auto epi = [&](int mt, const f32x4 &acc, int i) {
                 xr[i] = relu4(acc + bv + xr[i]);                                // add([x, block_input]) then ReLU; the input from registers
-                if (C::DUP && half && i == 0) return;                           // ... and stored by the first half only
                 lds_store4(xown, i * 16 * LDX, xr[i]);
             };
             NET_STAMP2(1);
-            gemm_tiles<F64, 2, CCSP_NET_SEG_L3>(wb, (LAY.l3_w[0] + wo), nt, mt0, pre, afrag, [&]() {
+            auto next = [&]() {
                 NET_STAMP2(2);
                 // (no branch: the same three loads either way -- the next block's first 1x1 or, behind the last block, the policy conv)
                 prefetch<4>(wb, blk < 8 ? LAY.l1_w[0] + wo + BLK_STRIDE : LAY.pc_w, blk < 8 ? nt2 : 0, pre);
-            }, epi);
+            };
+            if (F64B == F64 || half == 0) gemm_tiles<F64, 2, CCSP_NET_SEG_L3>(wb, (LAY.l3_w[0] + wo), nt, mt0, pre, afrag, next, epi);
+            else gemm_tiles<F64B, 2, CCSP_NET_SEG_L3>(wb, (LAY.l3_w[0] + wo), nt, mt0, pre, afrag, next, epi);
             NET_STAMP2(3);
         }
         __syncthreads();
