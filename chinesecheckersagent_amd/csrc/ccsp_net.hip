@@ -251,7 +251,9 @@ struct Smem {
     static_assert(C::MT * 16 * 16 <= C::PADROWS * LDY && C::HB * 400 <= C::PADROWS * LDY, "the policy conv output aliases y1");
     static_assert(256 + C::HB * (NPOL_PAD + 32) <= Y2N, "logits and value scratch alias y2");
 };
+#ifndef CCSP_NET_NO_LDS_ASSERT              // (layout experiments)
 static_assert(sizeof(Smem<Cfg<8, 8>>) + 3 * 6900 <= 160 * 1024, "<8,8>: one evaluator workgroup per CU plus three tree-kernel workgroups");
+#endif
 static_assert(sizeof(Smem<Cfg<4, 4>>) + 3 * 6900 <= 160 * 1024, "<4,4>: an evaluator workgroup per CU plus three tree-kernel workgroups (two per CU no longer fit: the shape carries batches of at most one workgroup per CU)");
 static_assert(sizeof(Smem<Cfg<2, 8>>) <= 64 * 1024, "<2,8>: a small workgroup");
 static_assert(sizeof(Smem<Cfg<1, 8>>) <= 64 * 1024, "<1,8>: a small workgroup");
