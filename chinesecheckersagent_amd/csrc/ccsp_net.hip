@@ -499,13 +499,15 @@ __device__ __forceinline__ void gemm_ksplit(const f32x4 (&bq)[KB / NSH], int kpa
 // barriers cost more than the imbalance they remove, so the last row tile is not k-split but computed whole by the wave of
 // each column tile whose share comes last (kpart == NSPLIT - 1).  No tile of these layers is split, so every output is one
 // plain accumulation chain over k -- the same arithmetic for every row without the segment sums of gemm_tiles_split.
-template <int NMT, int KB, int NSPLIT, int NSEG, typename AFrag, typename Next, typename Epi, typename EpiX>
+// MINE_C: 0 / 1 = the answer is a template constant (the caller holds a copy of the layer for either: straight-line code, the last
+// tile's MFMAs interleaved with the others'), -1 = decided by kpart at run time (one scalar branch per k-block).
+template <int NMT, int KB, int NSPLIT, int NSEG, int MINE_C, typename AFrag, typename Next, typename Epi, typename EpiX>
 __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int nt, int mt0, int xmt, int kpart, f32x4 (&pre)[NPREMAX],
                                                 AFrag afrag, Next next, Epi epi, EpiX epix) {
     constexpr int NPRE = Pre<KB>::N;
     constexpr int PB = NPRE + 1 < KB ? NPRE + 1 : KB;
     static_assert(NSEG >= 1 && NSEG <= KB, "a segment is at least one k-block");
-    const bool mine = kpart == NSPLIT - 1;                              // wave-uniform
+    const bool mine = MINE_C < 0 ? kpart == NSPLIT - 1 : MINE_C != 0;   // wave-uniform
     f32x4 acc[NMT + 1][NSEG];
 #pragma unroll
     for (int i = 0; i <= NMT; i++)
@@ -518,7 +520,7 @@ __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int n
     f32x4 a[2][NMT + 1];
 #pragma unroll
     for (int i = 0; i < NMT; i++) a[0][i] = afrag(mt0 + i, 0, i);
-    a[0][NMT] = afrag(xmt, 0, NMT);
+    if (MINE_C != 0) a[0][NMT] = afrag(xmt, 0, NMT);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
         int seg = 0;                                                    // static after unrolling
@@ -527,7 +529,7 @@ __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int n
         if (kb + 1 < KB) {
 #pragma unroll
             for (int i = 0; i < NMT; i++) a[(kb + 1) & 1][i] = afrag(mt0 + i, kb + 1, i);
-            a[(kb + 1) & 1][NMT] = afrag(xmt, kb + 1, NMT);
+            if (MINE_C != 0) a[(kb + 1) & 1][NMT] = afrag(xmt, kb + 1, NMT);
         }
         if (kb + PB - 1 < KB && kb + PB - 1 >= NPRE) bq[(kb + PB - 1) % PB] = wb.load(w0 + (kb + PB - 1) * 256);
         const f32x4 b = bq[kb % PB];
@@ -536,8 +538,9 @@ __device__ __forceinline__ void gemm_tiles_last(const WBuf &wb, int wbase, int n
 #pragma unroll
             for (int i = 0; i < NMT; i++)
                 acc[i][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][i][j], acc[i][seg], 0, 0, 0);   // D^T: see tile_out
+            if (MINE_C > 0) acc[NMT][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], acc[NMT][seg], 0, 0, 0);
         }
-        if (mine) {                                                     // ONE scalar branch per k-block
+        if (MINE_C < 0 && mine) {                                       // ONE scalar branch per k-block
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 acc[NMT][seg] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kb & 1][NMT][j], acc[NMT][seg], 0, 0, 0);
@@ -797,8 +800,15 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                 };
                 if (kh == 0) gemm_tiles<1, 4, CCSP_NET_SEG_L1>(wb, (LAY.l1_w[0] + wo), nt2, mt3, pre, afrag, []() {}, epi1);
             } else
-            gemm_tiles_last<F32A, 4, NSPLIT, CCSP_NET_SEG_L1>(wb, (LAY.l1_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, [&]() { prefetch<18>(wb, (LAY.l2_w[0] + wo), nt2, pre); },
-                                            epi, epix);
+            {
+                auto next = [&]() { prefetch<18>(wb, (LAY.l2_w[0] + wo), nt2, pre); };
+                if constexpr (CM && NB < 8) {                    // a copy of the layer with the last tile, one without (gemm_tiles_last).  A/B on one
+                                                                 // box, round 5: <4,4> 68.3 -> 67.7 us per 1024 positions; <8,8> (two waves per SIMD) 103.8 -> 105.3: not there
+                    if (kshare == NSPLIT - 1) gemm_tiles_last<F32A, 4, NSPLIT, CCSP_NET_SEG_L1, 1>(wb, (LAY.l1_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, next, epi, epix);
+                    else gemm_tiles_last<F32A, 4, NSPLIT, CCSP_NET_SEG_L1, 0>(wb, (LAY.l1_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, next, epi, epix);
+                } else
+                    gemm_tiles_last<F32A, 4, NSPLIT, CCSP_NET_SEG_L1, -1>(wb, (LAY.l1_w[0] + wo), nt2, mt3, MT - 1, kshare, pre, afrag, next, epi, epix);
+            }
         }
         __syncthreads();
         NET_STAMP(2 + 3 * blk);
