@@ -303,7 +303,10 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
 // A layer's FIRST weight k-blocks arrive in `pre` (NPRE of them, requested by the previous layer before its epilogue and
 // its barrier: an L2 round trip is a sixth of a 1x1 layer's MFMA time); next() is called once the last k-block's MFMAs
 // are issued and requests the following layer's.
-constexpr int NPREMAX = 3;
+#ifndef CCSP_NET_NPRE
+#define CCSP_NET_NPRE 3
+#endif
+constexpr int NPREMAX = CCSP_NET_NPRE;
 template <int KB> struct Pre { static constexpr int N = KB < NPREMAX ? KB : NPREMAX; };
 template <int KBN>
 __device__ __forceinline__ void prefetch(const WBuf &wb, int wbase, int nt, f32x4 (&pre)[NPREMAX]) {
