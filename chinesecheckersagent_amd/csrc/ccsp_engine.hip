@@ -1917,8 +1917,12 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     tally_flush(P, tl);
 }
 
+// Occupancy hint = VGPR budget (512 / waves, granule 8).  Two tree waves per SIMD run beside the evaluator's two: while net_forward_kernel<8,8>
+// took 174 (176) VGPRs that left 2 x 80 (hint 6: one 8-byte spill per simulation); at its 158 (160) of round 5 there are 2 x 96 -- hint 5: 90
+// VGPRs, no scratch (A/B on one box: 22.91 -> 22.97-23.06 M node-expansions/s).  ccsp_net.hip asserts nothing about this: check
+// tools/isa_resources.py when either kernel's registers change.
 #ifndef CCSP_ADVANCE_WAVES
-#define CCSP_ADVANCE_WAVES 6
+#define CCSP_ADVANCE_WAVES 5
 #endif
 struct AdvArgs {                  // advance_kernel's arguments (see the kernel's first lines)
     Params P;
