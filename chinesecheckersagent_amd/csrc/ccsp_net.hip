@@ -4,7 +4,8 @@
 // the reference's own arithmetic type) GEMM whose weights (BatchNorm folded in at load time) stream from L2
 // in a pre-packed per-lane order.  Replaces ~90 MIOpen/elementwise launches per forward.
 //
-//   rows = position * 25 + (r * 5 + c)    (200 rows per workgroup, padded to 13 tiles of 16)
+//   rows = position * 25 + (r * 5 + c), or -- <8,8> and <4,4>, round 5 -- cell-major (Cfg::CELLMAJOR): 200 rows per workgroup of 8
+//   positions, padded to 13 tiles of 16
 //   stem   3x3 valid 7->64      : A = implicit im2col of the 7x7x7 planes      K = 9 taps x 8 (7 + zero pad)
 //   block  1x1 64->32, 3x3 same 32->32 (implicit im2col with zero halo), 1x1 32->64 + residual, ReLU each
 //   policy 1x1 64->16, flatten (h, w, c) 400 -> dense 294 logits               (M = positions)
@@ -14,8 +15,9 @@
 // Inner loops carry NO vector-ALU instruction besides the MFMAs: on gfx950 the fp32 MFMA shares the SIMD's fp32 lanes
 // with ordinary VALU work, and every v_cndmask / v_add between MFMAs was measured to cost 10-15 cycles of matrix pipe
 // (tools/probe/mfma_probe.hip: 99.7 % of the pipe on bare MFMAs, 67 % with one v_cndmask per MFMA).  Hence: the 3x3
-// layers read their input from a copy with a ZERO HALO instead of masking taps, weights come through buffer loads whose
-// addresses are scalar (SGPR offset + immediate), and the k-split's extra MFMAs sit behind one scalar branch per k-block.
+// layers read their input from a copy with a ZERO HALO instead of masking taps (and, with cell-major rows, skip the k-blocks of an edge
+// tile that would read nothing but halo), weights come through buffer loads whose addresses are scalar (SGPR offset + immediate), and
+// the k-split's extra MFMAs sit behind one scalar branch per k-block or, where the layer is specialised per row group, behind none.
 // The weights are the MFMA's FIRST operand (tile_out below): a lane ends up with four consecutive channels of one row.
 // An evaluation is a function of the position alone: every output is formed by the same chains in the same order
 // whatever the batch size, the slot in the batch or the row tile (gemm_tiles_split).
@@ -128,17 +130,17 @@ static_assert(PLAIN_TOTAL == 244920, "249852 parameters minus the 4 x 1233 Batch
 // one zero row of six (the bottom halo of this map AND the top halo of the next).  Neighbour (dr, dc) = + 6 dr + dc.
 constexpr int PAD0 = 7, PADPOS = 36;
 // A workgroup of NW waves carries NB positions (rows = position * 25 + cell, MT tiles of 16 rows).  Four shapes are built:
-//   <8, 8>: 200 rows = 13 tiles (4 % padding), one 137-KB workgroup per CU, two waves per SIMD from the SAME workgroup --
+//   <8, 8>: 200 rows = 13 tiles (4 % padding), one 132-KB workgroup per CU, two waves per SIMD from the SAME workgroup --
 //           at every barrier both are out of matrix work at once;
-//   <4, 4>: 100 rows = 7 tiles (12 % padding), 72 KB, four waves: a workgroup is done in 0.6 of the time -- the shape of batches that
+//   <4, 4>: 100 rows = 7 tiles (12 % padding), 78 KB, four waves: a workgroup is done in 0.65 of the time -- the shape of batches that
 //           do not fill the GPU (up to 1024 positions), whose launch is as long as one workgroup;
-//   <2, 8>: 50 rows = 4 tiles (22 % padding), 51 KB, eight waves with ONE tile job each in the 32-column layers: the shape of
+//   <2, 8>: 50 rows = 4 tiles (22 % padding), 53 KB, eight waves with ONE tile job each in the 32-column layers: the shape of
 //           the smallest batches (one game of selfplay(), the arena's few games per GPU), where only latency counts.
 // Tile shares: 64-column layers -- wave & 3 = column tile, F64 (second half: F64B) row tiles from M64 * (wave >> 2) (until round 5 the two halves of <8, 8> both
 // compute tile 6); 32-column layers -- wave & 1 = column tile, F32 row tiles from F32 * (wave >> 1) plus, where the tiles do not
 // divide (XT), a 1/NSPLIT share of the k-range of the last tile MT - 1.  Every shape forms every output by the same chains in the
 // same order: a position's result does not depend on the shape.
-//   <1, 8>: 25 rows = 2 tiles, 26 KB, eight waves on ONE position (round 5): every tile job of the 3x3 layers is shared by TWO waves
+//   <1, 8>: 25 rows = 2 tiles, 53 KB (the heads' scratch for four positions), eight waves on ONE position (round 5): every tile job of the 3x3 layers is shared by TWO waves
 //           (half the k-range = two of the four segments each), the 1x1 layers have a job for every wave or every second one -- half the
 //           matrix work per CU of <2, 8>: the shape of the batches whose whole launch is ONE workgroup per CU and nothing but latency
 //           (one game of selfplay(), the arena's and config 5's few dozen slots per GPU: up to 256 positions).
