@@ -2188,8 +2188,12 @@ __global__ __launch_bounds__(64) void set_positions_kernel(Params P, const ccsp_
 
 // ccsp_advance's three limits (see ccsp_set_advance_limits below): the process-wide defaults a context starts with
 static int g_advance_budget = 8;
-static int g_advance_time_cap = 5000;    // 10-ns ticks; 0 = none
-static int g_advance_deadline = 8000;    // 10-ns ticks; 0 = none
+#ifndef CCSP_ADVANCE_TIME_CAP
+#define CCSP_ADVANCE_TIME_CAP 5000
+#define CCSP_ADVANCE_DEADLINE 8000
+#endif
+static int g_advance_time_cap = CCSP_ADVANCE_TIME_CAP;    // 10-ns ticks; 0 = none
+static int g_advance_deadline = CCSP_ADVANCE_DEADLINE;    // 10-ns ticks; 0 = none
 
 struct ccsp_ctx {
     ccsp_config cfg;
