@@ -62,6 +62,44 @@ def structure_bytes_per_expansion(D, K):
     return 20.0 * D * K + 26.0 * K + 30.0 * D + 72.0
 
 
+def net_roofline(n_pos, launch_ms, isolated_ms, wall_ms_per_launch, step_ms_per_launch, asked_rows_per_s_per_gpu, samples=0,
+                 tree_ms=None, launches=None, asked_rows_in_isolated_batch=None):
+    """`roofline` of the dominant kernel, net_forward_kernel, against the dense fp32 MFMA peak -- arithmetic a reader can redo from the
+    committed rocprof summary (profiles/*_bench_kernel_stats.csv):
+
+        FLOP per launch = n_pos x 6 483 264 (the ALGORITHMIC count, zero-padded taps included)
+        achieved = FLOP per launch / launch_ms       launch_ms = the launch's OWN duration as the product runs it: median of the launches of
+        frac     = achieved / 157.3 TFLOP/s          the timed region's uncaptured rounds, between HIP events on the launching stream, the
+                                                     other half-batch's graphs running beside it (rocprofv3's in-pipeline average is the
+                                                     same quantity); no sample -> the wall time per launch
+    Beside it, each under its own key: the same by the WALL time of the timed rounds per launch (`frac_by_wall`: gaps count against the
+    kernel, overlap between the two half-batches' launches counts for it), by the driver's clock over the whole timed region
+    (`frac_by_step`), for the rows that were ASKED only (`useful_frac_by_step`: idle rows carry no useful FLOP), and of the kernel alone
+    (`frac_isolated`: a back-to-back burst with nothing else on the device)."""
+    flop = float(n_pos) * NET_FLOP_PER_EVAL
+    own = launch_ms if launch_ms else wall_ms_per_launch
+
+    def tflops(ms):
+        return flop / (ms * 1e-3) / 1e12
+
+    def frac(ms):
+        return tflops(ms) / MFMA_F32_PEAK_TFLOPS
+    return {
+        'bound': 'mfma', 'achieved': tflops(own), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': frac(own), 'traffic': None,
+        'useful_frac_by_step': asked_rows_per_s_per_gpu * NET_FLOP_PER_EVAL / 1e12 / MFMA_F32_PEAK_TFLOPS,
+        'frac_by_step': frac(step_ms_per_launch), 'frac_by_wall': frac(wall_ms_per_launch), 'frac_isolated': frac(isolated_ms),
+        'dtype': 'fp32', 'kernel': 'net_forward_kernel', 'flop_per_position': NET_FLOP_PER_EVAL, 'positions_per_launch': int(n_pos),
+        'avg_launch_ms': own, 'avg_launch_ms_isolated': isolated_ms, 'achieved_isolated': tflops(isolated_ms),
+        'wall_ms_per_launch': wall_ms_per_launch, 'step_ms_per_launch': step_ms_per_launch,
+        'launches_in_flight': own / wall_ms_per_launch,       # > 1: consecutive launches of the two half-batches overlap
+        'how': ('frac = FLOP per launch / avg_launch_ms / peak; avg_launch_ms: median of %d launches inside the timed region, HIP events on the '
+                'launching stream, the other half-batch running beside them' % samples) if launch_ms else
+               'frac = FLOP per launch / (wall time of the timed rounds / evaluator launches in them) / peak (no uncaptured round to put events around)',
+        'launches_in_timed_region_per_gpu': launches, 'tree_kernels_ms_in_the_same_rounds': tree_ms,
+        'asked_rows_in_isolated_batch': asked_rows_in_isolated_batch,
+    }
+
+
 # ---- multi-GPU launcher ---------------------------------------------------------------------------------------------
 
 def _free_port():
@@ -535,8 +573,6 @@ def main():
     k_in_local = info.get('net_in_pipeline_ms') or (info['t_play'] / (info['steps'] * (S + 1) * info['parts']) * 1e3)
     k_in_all = max_over_ranks(k_in_local)
 
-    def max_over_ranks_in(_):
-        return k_in_all
     out = None
     if rank == 0:
         ex = tot3['expansions']
@@ -547,7 +583,9 @@ def main():
         hits = tot3.get('cache_hits', 0)
         rows_carried = steps * (S + 1) * info['n_slots'] * world        # rows of all evaluator launches of the timed region
         out = {
-            'metric': 'mcts_node_expansions_per_s (self-play with the policy/value net, %d games x %d sims/move per GPU; games/s: config.games_per_s)' % (G, S),
+            'metric': 'mcts_node_expansions_per_s (self-play with the policy/value net, %d games x %d sims/move per GPU); BASELINE games/s = '
+                      'config.games_per_s: selfplay() calls that RETURNED per second, discarded ones included (train.py:61-64 counts them); '
+                      'config.games_won_per_s: those that returned a history' % (G, S),
             'value': ex / dt3, 'unit': 'node-expansions/s', 'n_gpus': world, 'steps': steps, 'steps_requested': K, 'warmup': W,
             'ms_per_step': dt3 / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'degraded': False,
@@ -591,47 +629,16 @@ def main():
             'train_rows_written': rows_all, 'train_file_bytes': bytes_all,
             'timed_region_s': {'total': dt3, 'plies': info['t_play'], 'final_harvest_and_conversion': info['t_drain'], 'hdf5_close': info['t_write']},
             'ms_per_sim_step': info['t_play'] / steps / (S + 1) * 1e3,
-            'net_tflops_end_to_end': ex * NET_FLOP_PER_EVAL / dt3 / 1e12 / world,
+            # FLOP of the evaluator rows that were ASKED for (expansions answered by the previous ply's tree ran no evaluator), per GPU
+            'net_tflops_end_to_end': (ex - hits) * NET_FLOP_PER_EVAL / dt3 / 1e12 / world,
             'mean_depth': tot3['sum_depth'] / max(tot3['sims'], 1), 'mean_children': tot3['sum_children'] / max(ex, 1),
             'errors': tot3['errors'], 'per_rank_expansions': per3, 'precision': 'fp32', 'backend': info['backend'],
             'target_node_expansions_per_s_per_gpu': 1e6,
-            # `achieved` / `frac` describe the kernel AS THE PRODUCT RUNS IT.  `avg_launch_ms` = the median duration of the evaluator launches
-            # of the timed region's uncaptured steps (one per half-batch and timed ply), each between two HIP events on the stream it is
-            # launched on, while the other half-batch's captured graphs -- evaluator and tree kernels -- run beside it; rocprofv3's
-            # average over the same run (profiles/r4_bench_kernel_stats.csv) agrees with it.  Since the tree kernels of a round are shorter
-            # than an evaluator launch, the two half-batches' evaluator launches OVERLAP (profiles/r4_launches.csv: the next launch
-            # starts ~28 us before the previous one ends): each then shares the matrix pipes with the other and its own duration says how
-            # long it was in flight, not how much of the device it used.  `launches_in_flight` = avg_launch_ms / wall_ms_per_launch (the
-            # timed plies' wall time / evaluator launches in them); above 1 the device time a launch consumed is its duration divided
-            # by that number (= the wall time per launch: gaps between launches count against the kernel), which is what `achieved` is
-            # computed from; at or below 1 (no overlap) from the launch's own duration.  Kept beside it: the figure by a launch's own
-            # duration whatever the overlap (*_by_launch_duration) and the kernel alone (*_isolated: a back-to-back burst after the timed region).
-            'roofline': (lambda k_in, wall_ms: (lambda eff_ms: {
-                         'bound': 'mfma', 'dtype': 'fp32', 'kernel': 'net_forward_kernel',
-                         'achieved': info['n_pos'] * NET_FLOP_PER_EVAL / (eff_ms * 1e-3) / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s',
-                         'frac': info['n_pos'] * NET_FLOP_PER_EVAL / (eff_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         'traffic': None,
-                         'flop_per_position': NET_FLOP_PER_EVAL, 'positions_per_launch': info['n_pos'],
-                         'avg_launch_ms': k_in,
-                         'launches_in_flight': k_in / wall_ms,
-                         'device_ms_per_launch': eff_ms,
-                         'how': ('avg_launch_ms: median of %d launches inside the timed region, HIP events on the launching stream, the other half-batch running beside them; '
-                                 'achieved = FLOP per launch / (avg_launch_ms / max(1, launches_in_flight))' % info['net_in_pipeline_samples'])
-                                if info.get('net_in_pipeline_ms') else
-                                'wall time of the timed plies / evaluator launches in them (no uncaptured step to put events around)',
-                         'launches_in_timed_region_per_gpu': launches,
-                         'frac_by_launch_duration': info['n_pos'] * NET_FLOP_PER_EVAL / (k_in * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         'achieved_isolated': tf, 'frac_isolated': tf / MFMA_F32_PEAK_TFLOPS, 'avg_launch_ms_isolated': k_ms,
-                         'tree_kernels_ms_in_the_same_rounds': info.get('tree_in_pipeline_ms'),      # advance (+ boundary) of the timed round, same events
-                         'wall_ms_per_launch': wall_ms,
-                         'wall_frac': info['n_pos'] * NET_FLOP_PER_EVAL / (wall_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         # the same by the DRIVER's clock: the whole timed region (harvests, conversion, file close included) / launches
-                         'step_ms_per_launch': dt3 / launches * 1e3,
-                         'frac_by_step': info['n_pos'] * NET_FLOP_PER_EVAL / (dt3 / launches) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         'useful_frac_by_step': (ex - hits) / world * NET_FLOP_PER_EVAL / dt3 / 1e12 / MFMA_F32_PEAK_TFLOPS,   # rows that were asked for only
-                         'asked_rows_in_isolated_batch': info.get('asked_in_isolated_batch'),
-                         })(k_in / max(1.0, k_in / wall_ms)))(max_over_ranks_in(info), max(h[2] for h in host) / launches * 1e3),
+            # the dominant kernel against the fp32 MFMA peak: see net_roofline (frac = by the launch's own duration in the pipeline)
+            'roofline': net_roofline(info['n_pos'], info.get('net_in_pipeline_ms') and k_in_all, k_ms, max(h[2] for h in host) / launches * 1e3,
+                                     dt3 / launches * 1e3, (ex - hits) / dt3 / world, samples=info['net_in_pipeline_samples'],
+                                     tree_ms=info.get('tree_in_pipeline_ms'), launches=launches,
+                                     asked_rows_in_isolated_batch=info.get('asked_in_isolated_batch')),
         }
         try:                                 # HBM bytes of one launch by the counters (static: a --pmc pass cannot run inside this process)
             prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))['net_forward_kernel']
@@ -641,8 +648,11 @@ def main():
                 kbar = tot3['sum_children'] / max(ex, 1)
                 # request records in (64 B), their move rows in (2 K), compact priors and v out (8 K + 4), the weights once
                 out['roofline']['algorithmic_bytes_per_launch'] = info['n_pos'] * (64 + 2 * kbar + 8 * kbar + 4) + 4 * 250880
-        except (OSError, KeyError, ValueError) as ex:
-            out['roofline']['traffic_source'] = 'profiles/counters.json not usable: %r' % (ex,)
+        except (OSError, KeyError, ValueError) as err:
+            out['roofline']['traffic_source'] = 'profiles/counters.json not usable: %r' % (err,)
+        # the long-run share of discarded games, from WHOLE runs (every game played to its end: 32 768 games, profiles/r3_config4_rehearsal.txt;
+        # 8 192: 0.190) -- what `discard_rate` of a timed window tends to once the slots' games are spread over their whole length
+        out['discard_rate_of_whole_runs'] = {'value': 6292 / 32768.0, 'source': 'profiles/r3_config4_rehearsal.txt: 32 768 whole games, 6 292 discarded'}
         if tot3['errors']:
             raise SystemExit('config 3 counted %d engine errors' % tot3['errors'])
 

@@ -34,8 +34,8 @@ META_DTYPE = np.dtype([('game', '<u8'), ('ply', '<u4'), ('player', 'u1'), ('pad'
 RESULT_DTYPE = np.dtype([('status', 'u1'), ('reward', 'i1'), ('n_plies', '<u2'), ('n_samples', '<u4'),
                          ('expansions', '<u8')])
 # one record of the free-running path's request buffer (ccsp_request)
-REQUEST_DTYPE = np.dtype([('state', STATE_DTYPE), ('kind', '<u4'), ('depth', '<u4'), ('link', '<u4'), ('player', '<u4'), ('k', '<u4'),
-                          ('walk', '<u4', (3,))])
+REQUEST_DTYPE = np.dtype([('state', STATE_DTYPE), ('kind', '<u4'), ('reserved0', '<u4', (2,)), ('player', '<u4'), ('k', '<u4'),
+                          ('reserved1', '<u4', (3,))])
 assert STATE_DTYPE.itemsize == 32 and META_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 16 and REQUEST_DTYPE.itemsize == 64
 
 

@@ -288,6 +288,15 @@ __device__ __forceinline__ uint32_t *blk_N(uint8_t *b, int k) { return reinterpr
 __device__ __forceinline__ uint32_t *blk_child(uint8_t *b, int k) { return reinterpret_cast<uint32_t *>(b + BLOCK_HDR + 20 * k); }
 __device__ __forceinline__ uint16_t *blk_mv(uint8_t *b, int k) { return reinterpret_cast<uint16_t *>(b + BLOCK_HDR + 24 * k); }
 
+// Experiment switch (round 6): CCSP_TREE_NT = 1 gives the free-running path's block WRITES (wave_expand_answer,
+// wave_copy_block) a streaming cache policy, 2 also the old tree's reads of wave_copy_block and the selection's edge loads -- to see whether
+// the tree waves' traffic costs the evaluator beside them its weights in L2.  Default 0: measured, no gain (profiles/r6_tree_nt_ab.txt).
+#ifndef CCSP_TREE_NT
+#define CCSP_TREE_NT 0
+#endif
+template <typename T> __device__ __forceinline__ void st_blk(T *p, T v) { if (CCSP_TREE_NT >= 1) __builtin_nontemporal_store(v, p); else *p = v; }
+template <typename T> __device__ __forceinline__ T ld_old(const T *p) { return CCSP_TREE_NT >= 2 ? __builtin_nontemporal_load(p) : *p; }
+
 __device__ __forceinline__ uint64_t path_entry(uint32_t off8, int k, int j) { return ((uint64_t)off8 << 16) | ((uint64_t)k << 8) | (uint64_t)j; }
 
 // ---- B2-B4 for one position, wave-cooperative ----------------------------------------------------------
@@ -618,11 +627,11 @@ __device__ __forceinline__ int wave_expand_answer(Lds *lds, SimCtx &sl, uint8_t 
     for (int h = 0; h < 2; h++) {
         const int j = lane + 64 * h;
         if (j < K) {
-            blk_P(b, K)[j] = pr[h];
-            blk_W(b, K)[j] = 0.0;
-            blk_N(b, K)[j] = 0u;
-            blk_child(b, K)[j] = (m[h] & MV_WINS) ? CHILD_TERMINAL : CHILD_LEAF;
-            blk_mv(b, K)[j] = (uint16_t)(m[h] & 0x7FFFu);
+            st_blk(&blk_P(b, K)[j], pr[h]);
+            st_blk(&blk_W(b, K)[j], 0.0);
+            st_blk(&blk_N(b, K)[j], 0u);
+            st_blk(&blk_child(b, K)[j], (m[h] & MV_WINS) ? CHILD_TERMINAL : CHILD_LEAF);
+            st_blk(&blk_mv(b, K)[j], (uint16_t)(m[h] & 0x7FFFu));
         }
     }
     return K;
@@ -663,12 +672,12 @@ __device__ __forceinline__ Pick pick_edge(const double *__restrict__ sqrt_tab, c
             uint32_t o8 = 8u * (uint32_t)j, o4 = 4u * (uint32_t)j, o2 = 2u * (uint32_t)j;
             asm volatile("" : "+v"(o8), "+v"(o4), "+v"(o2));
             const uint8_t *e = b + BLOCK_HDR;
-            const double p = *reinterpret_cast<const double *>(e + o8);
-            const double w = *reinterpret_cast<const double *>(e + 8 * K + o8);
+            const double p = ld_old(reinterpret_cast<const double *>(e + o8));
+            const double w = ld_old(reinterpret_cast<const double *>(e + 8 * K + o8));
             wv[h] = w;
-            n[h] = *reinterpret_cast<const uint32_t *>(e + 16 * K + o4);
-            ch[h] = *reinterpret_cast<const uint32_t *>(e + 20 * K + o4);
-            mv[h] = *reinterpret_cast<const uint16_t *>(e + 24 * K + o2);
+            n[h] = ld_old(reinterpret_cast<const uint32_t *>(e + 16 * K + o4));
+            ch[h] = ld_old(reinterpret_cast<const uint32_t *>(e + 20 * K + o4));
+            mv[h] = ld_old(reinterpret_cast<const uint16_t *>(e + 24 * K + o2));
             double U, Q;
             if (RCP) {                                                               // same quotients, fewer instructions
                 const double dn = (double)n[h];
@@ -1760,11 +1769,11 @@ __device__ __forceinline__ int wave_copy_block(SimCtx &sl, uint8_t *pool, const 
     for (int h = 0; h < 2; h++) {
         const int j = lane + 64 * h;
         if (j < K) {
-            blk_P(b, K)[j] = reinterpret_cast<const double *>(ob + BLOCK_HDR)[j];
-            blk_W(b, K)[j] = 0.0;
-            blk_N(b, K)[j] = 0u;
-            blk_child(b, K)[j] = reinterpret_cast<const uint32_t *>(ob + BLOCK_HDR + 20 * K)[j] == CHILD_TERMINAL ? CHILD_TERMINAL : CHILD_LEAF;
-            blk_mv(b, K)[j] = reinterpret_cast<const uint16_t *>(ob + BLOCK_HDR + 24 * K)[j];
+            st_blk(&blk_P(b, K)[j], ld_old(&reinterpret_cast<const double *>(ob + BLOCK_HDR)[j]));
+            st_blk(&blk_W(b, K)[j], 0.0);
+            st_blk(&blk_N(b, K)[j], 0u);
+            st_blk(&blk_child(b, K)[j], ld_old(&reinterpret_cast<const uint32_t *>(ob + BLOCK_HDR + 20 * K)[j]) == CHILD_TERMINAL ? CHILD_TERMINAL : CHILD_LEAF);
+            st_blk(&blk_mv(b, K)[j], ld_old(&reinterpret_cast<const uint16_t *>(ob + BLOCK_HDR + 24 * K)[j]));
         }
     }
     return K;
@@ -1818,11 +1827,14 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     // a root request of THIS context is outstanding (bit 12 of word 15): only then does the record's kind mean anything -- the request
     // buffer is the caller's, and what it holds after a ccsp_reset / ccsp_set_positions is not to be trusted
     const bool asked = ((w15 >> 12) & 1) != 0;
-    const uint32_t kind = asked ? uni32(req[g].kind) : 0u;
+    // THE HAND-OFF STATE IS THE ENGINE'S OWN (P.pend): kind, k, and in advance_kernel depth / link / the walk to resume are read from the
+    // context's record, never from the caller's buffer -- `req` is an OUTPUT (position, kind, player, k: what an evaluator reads), so a
+    // caller's buffer that was swapped, re-used, mis-sized or scribbled on between two calls cannot send a wave out of its tree pool
+    const uint32_t kind = asked ? uni32(P.pend[g].kind) : 0u;
     // CCSP_ADVANCE_OVERLAPPED: this kernel runs BESIDE the evaluator launch that follows the call which wrote the request (the caller's
     // side stream), so that launch's answer is not to be trusted -- the next one's is: such a root request (kind 4) is two calls old
     // when its answer is taken.  In stream order (the default) the very next evaluator launch answers it (kind 3 at once).
-    if (kind == 4) { if (lane == 0) req[g].kind = 3; return; }
+    if (kind == 4) { if (lane == 0) { P.pend[g].kind = 3; req[g].kind = 3; } return; }
     // STAGGERED START: every slot's first game would begin in the same call and -- plies taking similar numbers of calls -- the slots
     // would end their plies in waves for dozens of plies: calls in which most slots are at the cheap middle of a search alternate with
     // calls in which most are at its expensive start (the reused top of the tree: simulation after simulation without the
@@ -1847,7 +1859,7 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     Tally tl; tally_zero(tl);
     uint32_t request = 0, req_k = 0;
     if (kind == 3) {                                      // the evaluator's answer for this ply's root (root_expand_kernel): selfplay.py:117-124
-        const int K = (int)uni32(req[g].k);
+        const int K = (int)uni32(P.pend[g].k);
         uint8_t *pool = (half ? P.pool2 : P.pool) + (uint64_t)g * P.pool_stride;
         SimCtx cx; cx.hgame = sl.hgame; cx.ply = sl.ply; cx.root_k = 0; cx.player = sl.player; cx.pool_used = 0; cx.nsum_bias = 0;
         uint32_t off;
@@ -1903,13 +1915,15 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
         }
     }
     if (lane == 0) {
-        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(req + g);
-        if (request) {
+        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(req + g), *own = reinterpret_cast<ulonglong2 *>(P.pend + g);
+        if (request) {                                    // the caller's record: what an evaluator reads (position, kind, player, k)
             q[0] = make_ulonglong2(sl.st.occ0, sl.st.occ1);
             q[1] = make_ulonglong2(sl.st.a, sl.st.b);
         }
-        q[2] = make_ulonglong2((uint64_t)request, (uint64_t)~0u | ((uint64_t)sl.player << 32));
-        q[3] = make_ulonglong2((uint64_t)req_k, 0ULL);   // (no walk to resume)
+        q[2] = make_ulonglong2((uint64_t)request, (uint64_t)sl.player << 32);
+        q[3] = make_ulonglong2((uint64_t)req_k, 0ULL);
+        own[2] = make_ulonglong2((uint64_t)request, (uint64_t)~0u | ((uint64_t)sl.player << 32));      // the engine's own: kind, k (a root hangs nowhere,
+        own[3] = make_ulonglong2((uint64_t)req_k, 0ULL);                                                 // no walk to resume; its position is the slot's)
         if (request && model_sel) model_sel[g] = (uint8_t)(sl.player == 2 ? 1 : 0);    // whose model answers (selfplay.py:30,36,59)
     }
     write_w15(P, g, phase, half, root_shadow, fin, request != 0);
@@ -1953,7 +1967,9 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(AdvArgs
     const uint8_t *old = (half ? P.pool : P.pool2) + (uint64_t)g * P.pool_stride;
     uint64_t *path = P.path + (uint64_t)g * P.path_stride;
         uint32_t a_exp = 0, a_term = 0, a_sims = 0, a_depth = 0, a_children = 0, a_edges = 0, a_hits = 0, errors = 0;
-    Pending pd = load_pending_scalar(A.req + g);            // (phase 1: the record was written by this context's kernels)
+    // the hand-off state -- the leaf asked about, where its block hangs, the path length, a walk to resume -- is the ENGINE'S OWN record
+    // (P.pend, written by this context's kernels in an earlier launch): nothing the caller's request buffer holds is used as an address
+    Pending pd = load_pending_scalar(P.pend + g);
     const bool answered = pd.kind == 1;                   // the evaluator's answer for the leaf this slot asked about last time
     // a selection this slot gave up at the deadline of its last call: it goes on where it stopped (WalkFrom)
     WalkFrom walk; walk.c = pd.walk_c; walk.nsum = pd.walk_at >> 16; walk.level = answered ? 0 : (int)(pd.walk_at & 0xFFFFu);
@@ -2058,11 +2074,15 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(AdvArgs
                 __syncthreads();
                 req_k = (uint32_t)wave_request_moves<true>(lds, leaf, leaf_player, A.moves + (size_t)g * REQ_MV);
                 if (lane_id_here() == 0) {
-                    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(A.req + g);
-                    q[0] = make_ulonglong2(leaf.occ0, leaf.occ1);
-                    q[1] = make_ulonglong2(leaf.a, leaf.b);
-                    q[2] = make_ulonglong2(1ULL | ((uint64_t)(uint32_t)depth << 32), (uint64_t)link_off | ((uint64_t)(uint32_t)leaf_player << 32));
+                    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(A.req + g), *own = reinterpret_cast<ulonglong2 *>(P.pend + g);
+                    const ulonglong2 s0 = make_ulonglong2(leaf.occ0, leaf.occ1), s1 = make_ulonglong2(leaf.a, leaf.b);
+                    // the caller's record: position, kind, player, k -- what an evaluator reads; the engine's own: the same + depth and link
+                    q[0] = s0; q[1] = s1;
+                    q[2] = make_ulonglong2(1ULL, (uint64_t)(uint32_t)leaf_player << 32);
                     q[3] = make_ulonglong2((uint64_t)req_k, 0ULL);
+                    own[0] = s0; own[1] = s1;
+                    own[2] = make_ulonglong2(1ULL | ((uint64_t)(uint32_t)depth << 32), (uint64_t)link_off | ((uint64_t)(uint32_t)leaf_player << 32));
+                    own[3] = make_ulonglong2((uint64_t)req_k, 0ULL);
                 }
                 ADV_LAP(t_enc);
                 request = 1;
@@ -2105,10 +2125,11 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(AdvArgs
         d[16] = r_begin; d[17] = r_end; d[18] = (unsigned long long)spent | ((unsigned long long)request << 32); d[19] = a_depth;
     }
     if (lane == 0) {
-        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(A.req + g);
+        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(A.req + g), *own = reinterpret_cast<ulonglong2 *>(P.pend + g);
         if (request != 1) {                               // nothing asked: the search is done, the budget is spent, or a walk waits to be resumed
-            q[2] = make_ulonglong2(0ULL, 0ULL);
-            q[3] = make_ulonglong2((uint64_t)left_c << 32, (uint64_t)left_at | ((uint64_t)left_edges << 32));
+            q[2] = make_ulonglong2(0ULL, 0ULL);           // (the caller's record: kind 0 = an idle evaluator row)
+            own[2] = make_ulonglong2(0ULL, 0ULL);
+            own[3] = make_ulonglong2((uint64_t)left_c << 32, (uint64_t)left_at | ((uint64_t)left_edges << 32));
         }
         if (request && A.model_sel) A.model_sel[g] = (uint8_t)(sl.player == 2 ? 1 : 0);    // whose model answers (selfplay.py:30,36,59)
         uint32_t *acc = P.stepacc + (size_t)g * 8;

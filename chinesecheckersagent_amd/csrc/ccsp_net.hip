@@ -1054,12 +1054,14 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
                     if (i < NPOL) pd[i] = e[j] / sum;
                 }
                 __builtin_amdgcn_wave_barrier();
-                const int k = (int)rq[s].k;
+                // (k and the move entries come from caller-owned buffers: k is clamped to the row, an entry that is no action index -- a row
+                // the engine has not written yet -- answers 0.0 instead of reading another wave's area)
+                const int k = (int)rq[s].k < CCSP_MAX_MOVES ? (int)rq[s].k : CCSP_MAX_MOVES;
                 const uint16_t *mrow = moves + (s0 + s) * CCSP_REQUEST_MOVES;
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int j = lane + 64 * h;
-                    if (j < k) p_out[(s0 + s) * CCSP_REQUEST_MOVES + j] = pd[mrow[j] & 0x1FF];
+                    if (j < k) { const int a = mrow[j] & 0x1FF; p_out[(s0 + s) * CCSP_REQUEST_MOVES + j] = a < NPOL ? pd[a] : 0.0; }
                 }
                 __builtin_amdgcn_wave_barrier();                // (the next position of this wave overwrites pd)
             }

@@ -386,8 +386,9 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_kernel(const ccsp_state *_
 __global__ __launch_bounds__(CCSP_REQUEST_MOVES) void gather_priors_kernel(const ccsp_request *__restrict__ req, const uint16_t *__restrict__ moves,
                                                                            const double *__restrict__ p, double *__restrict__ pk) {
     const int i = blockIdx.x, j = threadIdx.x;
-    if (req[i].kind == 0 || j >= (int)req[i].k) return;
-    pk[(size_t)i * CCSP_REQUEST_MOVES + j] = p[(size_t)i * CCSP_NUM_ACTIONS + (moves[(size_t)i * CCSP_REQUEST_MOVES + j] & 0x1FF)];
+    if (req[i].kind == 0 || j >= (int)req[i].k || j >= CCSP_MAX_MOVES) return;
+    const int a = moves[(size_t)i * CCSP_REQUEST_MOVES + j] & 0x1FF;         // (caller-owned rows: an entry that is no action index answers 0.0)
+    pk[(size_t)i * CCSP_REQUEST_MOVES + j] = a < CCSP_NUM_ACTIONS ? p[(size_t)i * CCSP_NUM_ACTIONS + a] : 0.0;
 }
 
 // test hook: spec.hash_eval / forward_eval / the uniform stub (the fused path's built-in evaluators) answering requests
@@ -399,8 +400,9 @@ __global__ __launch_bounds__(CCSP_REQUEST_MOVES) void table_eval_kernel(int eval
     const int player = (int)req[i].player;
     const uint64_t key = evaluator == CCSP_EVAL_HASH ? ccsp_state_key(st, player) : 0;
     if (j == 0) v[i] = evaluator == CCSP_EVAL_HASH ? ccsp_hash_value(key) : (evaluator == CCSP_EVAL_FORWARD ? ccsp_forward_value(st, player) : 0.0f);
-    if (j >= (int)req[i].k) return;
+    if (j >= (int)req[i].k || j >= CCSP_MAX_MOVES) return;
     const int idx = moves[(size_t)i * CCSP_REQUEST_MOVES + j] & 0x1FF;
+    if (idx >= CCSP_NUM_ACTIONS) { pk[(size_t)i * CCSP_REQUEST_MOVES + j] = 0.0; return; }
     pk[(size_t)i * CCSP_REQUEST_MOVES + j] = evaluator == CCSP_EVAL_HASH ? ccsp_hash_prior(key, idx)
                                             : (evaluator == CCSP_EVAL_FORWARD ? ccsp_forward_prior(st, player, idx / CCSP_NCELL, idx % CCSP_NCELL) : 1.0 / 294.0);
 }

@@ -53,14 +53,22 @@ def _batched(model):
     return model if hasattr(model, 'evaluate_batch') else _PredictAdapter(model)
 
 
+def _on_device(model):
+    """a batched evaluator that lives on the GPU (model.ResidualCNN), as opposed to a reference-style `.predict` object wrapped by
+    _PredictAdapter, which evaluates on the HOST one position at a time: nothing to capture in a hipGraph, and -- not being known to be a
+    pure function of the position -- nothing whose calls tree reuse may skip (selfplay.py:130-133 re-evaluates the subtree)"""
+    m = _batched(model)
+    return hasattr(m, 'model') and not isinstance(m, _PredictAdapter)
+
+
 _malloc_tuned = [False]
 
 
 def tune_host_allocator():
     """glibc serves every large array from a fresh mmap and gives it back on free: the harvest's copies, the float64 planes and the
     gathered pi rows of every conversion are then first-touch page faults -- measured 11 us per 2.7-KB row against 0.3 us once the heap
-    keeps its pages (mmap threshold 1 GB, no trimming).  Called once by SelfPlayRun (the rank processes of the N-GPU generator spend a
-    host core per GPU on conversion otherwise); CCSP_NO_MALLOPT=1 leaves the process's allocator alone."""
+    keeps its pages (mmap threshold 1 GB, no trimming).  Process-level state: called by the rank entry points (bench.py, launch.init_rank; the rank
+    processes of the N-GPU generator spend a host core per GPU on conversion otherwise) and by SelfPlayRun only under CCSP_MALLOPT=1; CCSP_NO_MALLOPT=1 leaves the process's allocator alone."""
     import os
     if _malloc_tuned[0] or os.environ.get('CCSP_NO_MALLOPT') == '1':
         return
@@ -147,8 +155,7 @@ class BatchSelfPlay(object):
         # one simulation step (select kernel -> net forward -> f64 softmax -> expand/backup kernel) is captured
         # once into a hipGraph and replayed `sims` times per ply: the step is launch-bound otherwise
         # (a reference-style .predict object evaluates on the HOST: nothing to capture)
-        on_device = lambda m: hasattr(m, 'model') and not isinstance(m, _PredictAdapter)
-        self.use_graph = bool(use_graph) and on_device(self.m1) and (self.m2 is None or on_device(self.m2))
+        self.use_graph = bool(use_graph) and _on_device(self.m1) and (self.m2 is None or _on_device(self.m2))
         self._graph = None
         self._root_is_p2 = torch.zeros(n_slots, dtype=torch.bool, device=dev)
         self.free_running = bool(free_running)
@@ -228,6 +235,26 @@ class BatchSelfPlay(object):
     DEBUG = False            # diagnostic tallies of ccsp_advance / ccsp_boundary in counters 12-14 (tools/bench_free.py --debug)
     SIDE_STREAM = False      # ccsp_boundary on a stream of its own beside the next evaluator launch (measured: hipGraphs with forks
                              # stop overlapping the two half-batches' graphs; kept for experiments)
+
+    def set_advance_limits(self, budget=-1, time_cap=-1, deadline=-1):
+        """ccsp_set_advance_limits for this batch.  The limits travel BY VALUE in every ccsp_advance launch, so a captured hipGraph keeps
+        the ones it was captured with: the graph is dropped here and captured again by the next play_steps (the same goes for a change of
+        BOUNDARY_EVERY, whose cadence is laid down at capture time).  Results do not depend on the limits."""
+        self.eng.set_advance_limits(budget, time_cap, deadline)
+        if self.free_running and self._graph is not None:
+            self.torch.cuda.synchronize(self.planes.device)
+            self._graph = None
+            self._graph_out = None
+
+    def set_advance_limits(self, budget=-1, time_cap=-1, deadline=-1):
+        """ccsp_set_advance_limits for this batch.  The limits travel BY VALUE in every ccsp_advance launch, so a captured hipGraph keeps
+        the ones it was captured with: the graph is dropped here and captured again by the next play_steps (the same goes for a change of
+        BOUNDARY_EVERY, whose cadence is laid down at capture time).  Results do not depend on the limits."""
+        self.eng.set_advance_limits(budget, time_cap, deadline)
+        if self.free_running and self._graph is not None:
+            self.torch.cuda.synchronize(self.planes.device)
+            self._graph = None
+            self._graph_out = None
 
     def _answer(self, m):
         """(pk, v): model m's compact answers to the requests on the table"""
@@ -667,7 +694,7 @@ class SelfPlayRun(object):
             # one part free-running / two parts lock-step / two parts free-running: 512 slots 8.1 / 7.1 / 5.7 / 6.4; 1024 slots
             # 10.5 / 10.4 / 10.9 / 11.6; 2048 slots - / - / 12.7 / 15.8: an evaluator launch of up to 512 positions takes 46 us, one of
             # up to 1024 76 us -- two halves of 512 overlap their tree work with each other's launch AND get the shorter launch)
-            n_parts = 2 if (n_slots >= 1024 and hasattr(_batched(model1), 'model')) else 1
+            n_parts = 2 if (n_slots >= 1024 and _on_device(model1)) else 1
         n_slots -= n_slots % n_parts
         self.n_games, self.n_slots, self.harvest_every = n_games, n_slots, int(harvest_every)
         kw = dict(sims=sims, seed=seed, first_game=first_game, game_stride=game_stride, max_games=n_games, randomised=randomised,
@@ -680,7 +707,9 @@ class SelfPlayRun(object):
             # 1194, 256 slots 4954 / 4219 (a sixth to a fifth of the free-running expansions come from the previous tree; its round is
             # 48 us against 43 for one slot, 72 against 52 for 256) -- so: free-running for a handful of slots (one game of selfplay():
             # the reused positions are worth more than the longer round) and from about a thousand on (4096: +30 %), lock-step between
-            free_running = n_slots >= 1024 or (n_slots <= 8 and model2 is None)
+            # -- for ON-DEVICE evaluators only: a host-side `.predict` object stays on lock-step (called exactly as often as the reference
+            # calls it, no encode / gather round trip per round) unless free_running / reuse is asked for explicitly
+            free_running = (n_slots >= 1024 or (n_slots <= 8 and model2 is None)) and _on_device(model1) and (model2 is None or _on_device(model2))
         if free_running and hasattr(_batched(model1), 'model'):
             # slots run at their own pace (BatchSelfPlay): between two harvests a slot plays up to ~1.5 plies per `play_ply`; a slot that
             # could find the log full waits for the harvest (log_guard) instead of losing a row
@@ -928,7 +957,7 @@ def generate_self_play(worker_id, model_path, num_self_play, model2_path=None, s
 
 def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model2_path=None, sims=MCTS_SIMULATIONS, seed=None,
                                    first_game=None, randomised=False, devices=None, as_arrays=False, out_dir=None, max_slots=MAX_SLOTS,
-                                   return_summary=False, timeout=None):
+                                   return_summary=False, timeout=None, max_steps=None, with_games=False):
     """train.generate_self_play_in_parallel (train.py:71-105) with GPUs for workers: `num_workers` rank processes, one per
     MI355X (devices[r], default r), are started from THIS process -- which never touches the GPU -- and play the ids
     first_game + j, j < num_self_play, sharded j mod num_workers; their counters and visit histograms meet in one RCCL
@@ -936,7 +965,10 @@ def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model
     order (as_arrays=True: utils.convert_to_train_data of that list as (board_x, pi_y, v_y) arrays, no object per position);
     with return_summary=True also the all-reduced summary {'counters': ..., 'visit_histogram': ...}.
     timeout (seconds): ranks still running after it are terminated (then killed) and the call raises, instead of waiting for ever on
-    a rank that stalls in a collective or a wedged kernel."""
+    a rank that stalls in a collective or a wedged kernel.
+    max_steps: every rank stops after that many steps (of sims + 1 rounds of all its slots) and hands back the games that have ENDED by
+    then -- a bounded rehearsal of a shape too long to play out (BASELINE config 4 on one device); with_games (as_arrays): the game id of
+    every row as a fourth array."""
     import json
     import os
     import sys
@@ -959,6 +991,8 @@ def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model
             argv += ['--model2', model2_path]
         if randomised:
             argv += ['--randomised']
+        if max_steps:
+            argv += ['--max-steps', str(int(max_steps))]
         if as_arrays:
             argv += ['--arrays']                          # the ranks stream (board_x, pi_y, v_y, game) into files: their memory stays bounded
         extra = {'PYTHONPATH': os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
@@ -979,9 +1013,9 @@ def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model
             if parts:
                 bx, py, vy, gid = (np.concatenate([x[i] for x in parts]) for i in range(4))
                 o = np.argsort(gid, kind='stable')          # games by id; a game's rows stay in ply order
-                out = (bx[o], py[o], vy[o])
+                out = (bx[o], py[o], vy[o]) + ((gid[o],) if with_games else ())
             else:
-                out = (np.zeros((0, 7, 7, 7)), np.zeros((0, NUM_ACTIONS)), np.zeros(0, dtype=np.int64))
+                out = (np.zeros((0, 7, 7, 7)), np.zeros((0, NUM_ACTIONS)), np.zeros(0, dtype=np.int64)) + ((np.zeros(0, dtype=np.int64),) if with_games else ())
             if return_summary:
                 with open(os.path.join(out_dir, 'summary.json')) as f:
                     return out, json.load(f)

@@ -41,9 +41,14 @@ def selfplay_rank(a):
                              first_game=a.first_game + rank, game_stride=world, device=local, max_slots=a.max_slots,
                              keep_records=not a.arrays, sink=sink)
         try:
-            run.run()
+            run.run(max_plies=a.max_steps if a.max_steps > 0 else None)      # (--max-steps: a bounded rehearsal leaves games unfinished)
             counters = run.counters()
             parts = run.b.parts if hasattr(run.b, 'parts') else [run.b]
+            # what this rank really ran on (the N-rank tests assert it: not a fallback)
+            out_path = dict(free_running=bool(run.free_running), n_slots=int(run.n_slots), half_batches=len(parts), steps=int(run.plies),
+                            reuse=all(bool(getattr(b, 'reuse', False)) for b in parts),
+                            graphs=all(getattr(b, '_graph', None) is not None for b in parts),
+                            backend=getattr(model, 'backend', None), finished=int(run.store.n_finished()))
             for b in parts:
                 hist += b.eng.visit_histogram()
             store = run.store
@@ -65,7 +70,8 @@ def selfplay_rank(a):
             run.close()
     ru = resource.getrusage(resource.RUSAGE_SELF)
     host = dict(rank=rank, wall_s=time.time() - t0, host_cpu_s=ru.ru_utime + ru.ru_stime, peak_rss_mb=ru.ru_maxrss / 1024.0,
-                rows=out.get('rows'), games=n_mine)
+                rows=out.get('rows'), games=n_mine, counters={k: int(v) for k, v in counters.items()},
+                visit_histogram_sum=int(hist.sum()), path=out_path if n_mine > 0 else None)
     with open(os.path.join(a.out, 'host-rank%d.json' % rank), 'w') as f:          # (what the N = 8 host-load rehearsal reads)
         json.dump(host, f)
     tot, hist_all = counters, hist
@@ -93,6 +99,7 @@ def main(argv=None):
     s.add_argument('--seed', type=int, required=True)
     s.add_argument('--first-game', type=int, default=0)
     s.add_argument('--max-slots', type=int, default=4096)
+    s.add_argument('--max-steps', type=int, default=0, help='stop after this many steps of sims + 1 rounds (0 = play every game to its end)')
     s.add_argument('--randomised', action='store_true')
     s.add_argument('--arrays', action='store_true', help='stream (board_x, pi_y, v_y, game) into DIR/selfplay-rank{r}.h5 instead of keeping the rows')
     s.add_argument('--out', required=True)

@@ -260,14 +260,16 @@ int ccsp_ply_end(ccsp_ctx *ctx, void *stream);
  *
  * THE HAND-OFF (what replaces the reference's call `model.predict(to_model_input(leaf))`, MCTS.py:93, for a whole batch):
  *   req    [n_slots] ccsp_request, device, CALLER-OWNED and zero-filled before the first call after ccsp_create / ccsp_reset /
- *          ccsp_set_positions; the SAME buffer in every call of a context (a record also carries the slot's hand-off state between calls).
+ *          ccsp_set_positions; the same buffer in every call of a context (a slot's record is rewritten only when its state changes).  The
+ *          engine only WRITES it: its own hand-off state is kept inside the context.
  *          A slot with kind != 0 asks for the evaluation of `state` with `player` to move: the 32-byte position record is all the
  *          evaluator needs (utils.to_model_input is a function of it: ccsp_net_forward_requests builds the 7 x 7 x 7 planes in its input
  *          phase; ccsp_encode_requests writes them out for evaluators that want planes) -- 64 bytes per request where float32 planes
  *          were 1372;
  *   moves  [n_slots][CCSP_REQUEST_MOVES] uint16, device, caller-owned, the same buffer in every call: the legal moves of `state` in
  *          Board.get_valid_moves' order (board.py:215-222), entry = action index (utils.encode_checker_index) | 0x8000 where the move wins;
- *          req.k entries.  The move list is generated when the request is made, not when the answer arrives;
+ *          req.k entries.  The move list is generated when the request is made and READ BACK when the answer arrives (zero-fill it too: the
+ *          evaluators answer 0.0 for an entry that is no action index);
  *   pk     [n_slots][CCSP_REQUEST_MOVES] float64, device: THE ANSWER, COMPACT -- pk[slot][j] = softmax(logits)[moves[slot][j] & 0x1FF], the
  *          prior of the j-th legal move (the reference reads p[encode_checker_index(...)] per legal move, MCTS.py:97-109, and nothing
  *          else of the 294 entries); v [n_slots] float32.  K x 8 bytes per answer where the full policy row was 2352.
@@ -293,11 +295,12 @@ int ccsp_ply_end(ccsp_ctx *ctx, void *stream);
 typedef struct ccsp_request {
     ccsp_state state;         /* the position to evaluate */
     uint32_t kind;            /* 0 = nothing asked; 1 = a leaf, 3 / 4 = a ply's root */
-    uint32_t depth, link;     /* the engine's own: path length, where the new node hangs */
+    uint32_t reserved0[2];    /* written as 0 */
     uint32_t player;          /* player to move in `state` (1 | 2) */
     uint32_t k;               /* legal moves of `state`: entries of moves[slot] and of pk[slot] */
-    uint32_t walk[3];         /* the engine's own: a selection to be resumed */
-} ccsp_request;
+    uint32_t reserved1[3];    /* written as 0 */
+} ccsp_request;               /* OUTPUT ONLY: the engine never reads a record back -- where a new node hangs, the path length and a selection
+                                 to be resumed live in the context's own memory, so nothing a caller's buffer holds is ever used as an address */
 enum { CCSP_ADVANCE_REUSE = 1, CCSP_ADVANCE_LOG_GUARD = 2, CCSP_ADVANCE_STAGGER = 4, CCSP_ADVANCE_DEBUG = 8 /* diagnostic tallies in counters 12-14 */,
        CCSP_ADVANCE_OVERLAPPED = 16, CCSP_ADVANCE_ALL_FLAGS = 31 };
 int ccsp_enable_tree_reuse(ccsp_ctx *ctx);
@@ -316,7 +319,9 @@ int ccsp_gather_priors(const ccsp_request *req, const uint16_t *moves, const dou
 /* test hook: the built-in table evaluators (CCSP_EVAL_UNIFORM / HASH / FORWARD) as an external evaluator of requests -> (pk, v) */
 int ccsp_debug_table_eval(int evaluator, const ccsp_request *req, const uint16_t *moves, int n, double *pk, float *v, void *stream);
 /* The three limits of ccsp_advance below, per context (a value < 1 / < 0 / < 0 leaves that one as it is).  A context starts with the
- * process-wide defaults, which the ccsp_debug_advance_* hooks change for contexts created AFTERWARDS. */
+ * process-wide defaults, which the ccsp_debug_advance_* hooks change for contexts created AFTERWARDS.  The limits are passed BY VALUE with
+ * every ccsp_advance launch: a caller that captures its rounds into a hipGraph must set them BEFORE the capture (a captured launch keeps the
+ * values it was captured with) or capture again afterwards -- selfplay.BatchSelfPlay.set_advance_limits drops its graph for that reason. */
 int ccsp_set_advance_limits(ccsp_ctx *ctx, int budget, int time_cap_ticks, int deadline_ticks);
 /* evaluator-free simulations (won leaves, reused positions) a slot takes up in ONE ccsp_advance before the selection that ends the call
  * (default 8; if that selection too ends on such a leaf the simulation is completed and the call ends without a request: bounds the launch's

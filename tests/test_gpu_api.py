@@ -622,6 +622,55 @@ def test_generate_self_play_in_parallel_world2_on_one_device(golden_dir):
     assert len(vy) == len(ov) > 0 and (bx == ox).all() and (py == op).all() and (vy == ov).all()
 
 
+def test_config4_shape_five_ranks_of_4096_free_running_slots_on_one_device(golden_dir, tmp_path):
+    """BASELINE config 4 AT ITS PER-RANK SHAPE on the one device of the box: train.generate_self_play_in_parallel (train.py:71-105) with FIVE
+    rank processes -- the most this process can start beside itself under the pool's limit of six GPU processes per card; the
+    stand-alone rehearsal (tools/config4_one_device.py, profiles/r6_config4_one_device.txt) runs six -- each with 4096 free-running slots
+    at 400 simulations (two half-batches, tree reuse, 25 rounds per hipGraph: what bench.py times on one GPU), ids sharded j mod 5, the
+    summary all-reduced over gloo, for a BOUNDED number of steps (max_steps: the whole shape would play for minutes on a shared device).
+    Checked: every rank really ran that path; the all-reduced counters and the 294-bin visit histogram are the sums of the ranks'; and
+    the games that ended -- at least 32 of them -- have exactly the rows a single-rank run of the same ids produces."""
+    import os
+    from chinesecheckersagent_amd import selfplay as sp
+    w = golden_dir + '/good_model.h5'
+    R, G, sims, seed, steps = 5, 4096, 400, 20261003, 56
+    out_dir = str(tmp_path)
+    (bx, py, vy, gid), summ = sp.generate_self_play_in_parallel(w, R * G * 2, R, sims=sims, seed=seed, first_game=0, devices=[0] * R, as_arrays=True,
+                                                                return_summary=True, out_dir=out_dir, max_slots=G, timeout=900,
+                                                                max_steps=steps, with_games=True)
+    ranks = [json.load(open(os.path.join(out_dir, 'host-rank%d.json' % r))) for r in range(R)]
+    for h in ranks:
+        pth = h['path']
+        assert pth['free_running'] and pth['reuse'] and pth['graphs'] and pth['backend'] == 'hip', pth      # the measured path, not a fallback
+        assert pth['n_slots'] == G and pth['half_batches'] == 2 and pth['steps'] == steps
+        assert h['counters']['errors'] == 0 and h['counters']['cache_hits'] > 0.15 * h['counters']['expansions']
+    c = summ['counters']
+    assert summ['world'] == R and summ['backend'] == 'gloo' and c['errors'] == 0
+    for k in c:                                                  # the one collective of the path: all-reduce(sum) of counters + histogram
+        assert c[k] == sum(h['counters'].get(k, 0) for h in ranks), k
+    assert sum(summ['visit_histogram']) == sum(h['visit_histogram_sum'] for h in ranks) == c['mcts_plies'] * sims
+    assert c['expansions'] > R * G * steps * 0.5 * (sims + 1) * 0.2                  # (every rank's slots were really searching)
+    ended = np.unique(gid)
+    assert c['games_won'] == len(ended) >= 32 and len(vy) == len(gid) > 0
+    # the same ids on ONE rank in this process: slot s plays ids s, s + 4096 -- the first of which five-rank slot (s - r) / 5 of rank s mod 5 played
+    m = ResidualCNN_loaded(w)
+    sink = sp.TrainDataSink()
+    run = sp.SelfPlayRun(m, n_games=G * 2, sims=sims, seed=seed, max_slots=G, keep_records=False, sink=sink)
+    try:
+        run.run(max_plies=steps)
+        assert run.free_running and run.counters()['errors'] == 0
+    finally:
+        run.close()
+    ox, op, ov, og = sink.arrays(with_games=True)
+    common = np.intersect1d(ended, np.unique(og))
+    assert len(common) >= 32, len(common)
+    a, b = np.isin(gid, common), np.isin(og, common)
+    assert (gid[a] == og[b]).all() and (bx[a] == ox[b]).all() and (py[a] == op[b]).all() and (vy[a] == ov[b]).all()
+    print('config 4 shape on one device: %d ranks x %d slots x %d sims, %d steps: %d games ended, %d compared with one rank; wall per rank %s s, '
+          'host cores per rank %s, peak RSS %s MB' % (R, G, sims, steps, len(ended), len(common), [round(h['wall_s'], 1) for h in ranks],
+                                                      [round(h['host_cpu_s'] / h['wall_s'], 2) for h in ranks], [int(h['peak_rss_mb']) for h in ranks]))
+
+
 def ResidualCNN_loaded(path):
     from chinesecheckersagent_amd.model import ResidualCNN
     m = ResidualCNN()
@@ -629,16 +678,17 @@ def ResidualCNN_loaded(path):
     return m
 
 
-def _bench(extra, **envx):
+def _bench(extra, common=None, **envx):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    common = ['--sims', '24', '--steps', '3', '--warmup', '1', '--spread-plies', '6', '--min-seconds', '0', '--fused-plies', '3',
-              '--cpu-cores', '2', '--config5-games', '4', '--config5-sims', '8']
-    if '--cpu-seconds' not in extra:
-        common += ['--cpu-seconds', '0.4']
+    if common is None:
+        common = ['--sims', '24', '--steps', '3', '--warmup', '1', '--spread-plies', '6', '--min-seconds', '0', '--fused-plies', '3',
+                  '--cpu-cores', '2', '--config5-games', '4', '--config5-sims', '8']
+    if '--cpu-seconds' not in extra + common:
+        common = common + ['--cpu-seconds', '0.4']
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + extra + common, env=dict(env, **envx),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -685,6 +735,30 @@ def test_bench_launcher_world2_on_one_device(tmp_path):
     a, b = two['variants']['2a_fused_table_evaluator'], one['variants']['2a_fused_table_evaluator']
     assert sum(a['per_rank_expansions']) == b['per_rank_expansions'][0] and a['visit_histogram_sum'] == b['visit_histogram_sum']
     assert 'movegen_kernel' in one['variants'] and 'movegen_kernel' not in two['variants']
+
+
+def test_bench_five_ranks_on_one_device_at_400_sims():
+    """`python bench.py --gpus N` END TO END with as many ranks as a 1-GPU box lets this process start beside itself (five; the stand-alone
+    rehearsal runs six): every rank a free-running SelfPlayRun of 1024 slots at 400 simulations (two half-batches on captured
+    graphs -- CCSP_STRICT refuses anything else), variant 2a on every rank, and BASELINE config 5's N-rank loop (sharded self-play, DDP
+    fit with global-batch statistics, sharded arena, one gating decision) -- so that the driver's first real N-GPU run meets nothing for
+    the first time except RCCL itself (gloo carries the collectives here: RCCL refuses two ranks on one device)."""
+    import time
+    t0 = time.time()
+    doc = _bench(['--gpus', '5', '--games', '1024'],
+                 common=['--sims', '400', '--steps', '4', '--warmup', '1', '--spread-plies', '14', '--min-seconds', '0', '--fused-plies', '4',
+                         '--cpu-seconds', '0', '--config5-games', '40', '--config5-sims', '100', '--config5-timeout', '400'],
+                 CCSP_BENCH_ONE_DEVICE='1')
+    wall = time.time() - t0
+    assert doc['n_gpus'] == 5 and doc['degraded'] is False and doc['errors'] == 0 and doc['backend'] == 'hip'
+    assert len(doc['per_rank_expansions']) == 5 and min(doc['per_rank_expansions']) > 0
+    assert doc['config']['free_running'] is True and doc['config']['half_batches'] == 2 and doc['config']['tree_reuse_hit_rate'] > 0.1
+    assert len(doc['measured']['host_cpu_s_per_rank']) == 5
+    assert sum(doc['variants']['2a_fused_table_evaluator']['per_rank_expansions']) > 0
+    c5 = doc['config5']
+    assert 'failed' not in c5 and c5['selfplay_games'] == 40 and c5['train_s'] > 0 and 'arena_wins' in c5
+    print('bench.py --gpus 5 on one device (1024 slots x 400 sims per rank, config 5 with 40 games x 100 sims): wall %.1f s; headline %.2f M '
+          'node-expansions/s over all ranks; config 5 %.1f s' % (wall, doc['value'] / 1e6, c5['wall_s']))
 
 
 def test_bench_survives_a_rank_that_never_joins_config5():

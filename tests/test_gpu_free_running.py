@@ -135,6 +135,55 @@ def test_reference_games_through_advance_and_boundary(golden_dir, limits):
     assert hits > 10000                                         # ... and the reuse path really ran
 
 
+def test_request_buffer_is_output_only(golden_dir):
+    """The caller's request buffer is an OUTPUT of ccsp_advance / ccsp_boundary: where a new node hangs, the path length, a walk to be
+    resumed, even the leaf's position and k live in the context's own record.  After every evaluation this test overwrites each record's
+    position, k and reserved words with 0xFF bytes (kind and player stay: they say which rows the NEXT evaluation reads) -- what a caller
+    that re-uses, swaps or scribbles on its buffer does -- at one-tick limits, so that resumed walks are exercised too: the reference's
+    games come out bit for bit all the same (before round 6 the kernels took link offsets and walk state from these words)."""
+    import torch
+    from chinesecheckersagent_amd import _lib, engine
+
+    class Scribbler(FreeRunner):
+        def round(self):
+            e = self.e
+            self.answer()
+            w = self.req.view(torch.int32)                       # [n, 16]: state 0-7 | kind 8 | reserved 9, 10 | player 11 | k 12 | reserved 13-15
+            w[:, 0:8] = -1
+            w[:, 9:11] = -1
+            w[:, 12:16] = -1
+            e.advance(self.pk, self.v, self.req, self.moves, self.model_sel, reuse=self.reuse)
+            e.boundary(self.pk, self.v, self.req, self.moves, self.model_sel, reuse=self.reuse)
+            self.rounds += 1
+
+        def answer(self):
+            # (the records are read BEFORE the scribble of this round and after the engine's writes of the last one: whole again where kind != 0)
+            return FreeRunner.answer(self)
+    doc = json.load(open(golden_dir + '/games.json'))
+    seed = doc['seed']
+    games = sorted((g for g in doc['games'] if not isinstance(g['evaluator'], list)), key=lambda g: g['evals'])[:4]
+    hits = 0
+    for g in games:
+        e = engine.SelfPlayEngine(n_slots=1, sims=g['sims'], seed=seed, first_game=g['game'], max_games=1, log_capacity=1024, randomised=g['randomised'])
+        fr = Scribbler(e, g['evaluator'], reuse=True, limits=(64, 1, 1))
+        for i in range(400000):
+            fr.round()
+            if i % 64 == 63 and e.slots()['status'][0] != _lib.ST_RUNNING:
+                break
+        res, c = e.results()[0], e.counters()
+        assert {1: 'won', 2: 'won', 3: 'repetition', 4: 'no_progress'}[int(res['status'])] == g['status']
+        assert int(res['n_plies']) == len(g['plies']) and int(res['expansions']) == g['evals'] == c['expansions'] and c['errors'] == 0
+        assert fr.asked + c['cache_hits'] == g['evals']
+        hits += c['cache_hits']
+        st, meta, pi = e.log()
+        order = np.argsort(meta['ply'])
+        if g['status'] == 'won':
+            drop = 3 if g['randomised'] else 0
+            assert [_sha(np.asarray(r, dtype='<f8'))[:16] for r in pi[order][drop:]] == g['pi_sha']
+        e.close()
+    assert hits > 0
+
+
 @pytest.mark.parametrize('reuse', [True, False], ids=['reuse', 'no-reuse'])
 def test_reference_make_move_cases_through_advance_and_boundary(golden_dir, reuse):
     """(b) the 109 make_move() cases: ccsp_set_positions -> [answer -> advance -> boundary] until the slot's row is in the log; its root

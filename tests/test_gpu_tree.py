@@ -421,6 +421,46 @@ def test_full_size_invariants_and_oracle_sample(eng):
         assert np.array_equal(pi[r], np.array(o.pi[:])), 'row %d differs from the oracle' % r
 
 
+def test_config_2b_full_size_rollout_invariants_and_oracle_sample(eng):
+    """BASELINE configs[1] in its north-star wording (SURVEY.md 8d "2b": random-rollout value, uniform priors, no net) AT FULL SIZE: 4096
+    concurrent games x 400 simulations through the fused kernel with CCSP_EVAL_ROLLOUT for two searched plies -- the run bench.py's
+    `variants.2b_rollout` times.  No reference counterpart exists (MCTS.py:93 always calls the model): the definition is restated in
+    oracle/ccsp_oracle.c (evaluator 3).  Size-independent properties of every row, run-to-run determinism, and 24 rows -- both plies --
+    bit for bit against the CPU restatement at 400 simulations."""
+    import hashlib
+    from chinesecheckersagent_amd import _lib
+    G, S, seed = 4096, 400, 20261003
+
+    def run():
+        e = eng.SelfPlayEngine(n_slots=G, sims=S, seed=seed, max_games=G, log_capacity=G * 4)
+        e.play_plies(_lib.EVAL_ROLLOUT, 6)
+        e.play_plies(_lib.EVAL_ROLLOUT, 2)
+        st, meta, pi = e.log()
+        c = e.counters()
+        roots = {s: e.read_root(s) for s in range(0, G, 171)}
+        e.close()
+        order = np.lexsort((meta['ply'], meta['game']))
+        return st[order], meta[order], pi[order], c, roots
+    st, meta, pi, c, roots = run()
+    assert len(meta) == 2 * G and c['errors'] == 0
+    assert c['sims'] == 2 * G * S and c['expansions'] + c['terminal_sims'] == 2 * G * (S + 1)
+    assert np.abs(pi.sum(axis=1) - 1.0).max() < 1e-12 and (pi >= 0).all()
+    assert np.allclose(pi * S, np.round(pi * S), atol=1e-9)             # tau = 1: pi = N / 400
+    for s, r in roots.items():
+        assert int(r['N'].sum()) == S and len(set(int(m) for m in r['mv'])) == len(r['mv'])
+        assert np.abs(r['W']).max() <= S                                 # a playout's value is -1, 0 or +1
+    for r in range(0, 2 * G, 509):                                       # pi lives on legal moves only
+        legal = set(int(a) * 49 + int(b) for a, b in orc.movegen(st[r]['pos'].reshape(12), int(meta[r]['player'])))
+        assert set(int(i) for i in np.nonzero(pi[r])[0]) <= legal
+    digest = hashlib.sha256(st.tobytes() + pi.tobytes()).hexdigest()
+    st2, meta2, pi2, c2, _ = run()
+    assert hashlib.sha256(st2.tobytes() + pi2.tobytes()).hexdigest() == digest and c2 == c, 'two runs with one seed differ'
+    for r in range(0, 2 * G, 341):                                       # 24 rows, both plies, against the CPU restatement at 400 simulations
+        o = orc.search(st[r]['pos'].reshape(12), st[r]['last'], int(meta[r]['player']), seed, int(meta[r]['game']),
+                       int(meta[r]['ply']), S, False, 3)
+        assert np.array_equal(pi[r], np.array(o.pi[:])), 'row %d differs from the CPU restatement of the rollout evaluator' % r
+
+
 def test_config5_simulation_count_800(eng):
     """SURVEY.md §8d config 5 searches with 800 simulations per move: above the 510 that the reciprocal table in LDS
     covers, so the fused kernel takes its IEEE-division path and the wider tables -- same results, bit for bit"""

@@ -125,6 +125,22 @@ def test_summary_allreduce_gloo_world2():
         assert tot['expansions'] == 300 and tot['games_won'] == 10 and h == [7, 7, 2 ** 41]
 
 
+def test_summary_allreduce_gloo_world8():
+    """BASELINE config 4's world size: EIGHT ranks (on the CPU over gloo: a 1-GPU box admits six GPU processes, the N = 8 hardware run is
+    the driver's) -- id sharding j mod 8 covers every id once, the all-reduced counters and histogram are the sums over the eight"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 30600 + os.getpid() % 1000
+    ps = [ctx.Process(target=_rank_main, args=(r, 8, port, q)) for r in range(8)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=300) for _ in ps)
+    [p.join(60) for p in ps]
+    assert sorted(i for r in res for i in r[1]) == list(range(10)) and all(r[1] == list(range(r[0], 10, 8)) for r in res)
+    for _, _, tot, h in res:
+        assert tot['expansions'] == 100 * 36 and tot['games_won'] == 10 and h == [7, 7, 8 * 2 ** 40]
+
+
 def test_augment_train_data_matches_reference(golden_dir):
     """utils.augment_train_data incl. its un-mirrored pi (fixture made by the reference)"""
     from chinesecheckersagent_amd import utils
@@ -350,3 +366,22 @@ def test_the_hot_path_entry_is_guarded(monkeypatch, capsys):
         with pytest.raises(_lib.CcspError, match='hot path'):
             sp._check_hot_path(*args)
         monkeypatch.delenv('CCSP_STRICT')
+
+
+def test_bench_roofline_arithmetic_on_canned_numbers():
+    """bench.net_roofline (the `roofline` object of the bench line) on round 5's own figures: `frac` is FLOP per launch over the launch's OWN
+    duration -- the number a reader recomputes from profiles/*_bench_kernel_stats.csv -- and every other fraction sits under its own key"""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.net_roofline(2048, 0.11845, 0.10429, 0.11196, 0.11365, 17.11e6, samples=40, tree_ms=0.0839, launches=16040,
+                           asked_rows_in_isolated_batch=1950)
+    flop = 2048 * 6483264
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3 and r['traffic'] is None
+    assert abs(r['achieved'] - flop / 118.45e-6 / 1e12) < 1e-9 and abs(r['frac'] - 0.7126) < 5e-4          # rocprof's 118.45 us -> 0.713
+    assert abs(r['frac_isolated'] - 0.8094) < 5e-4 and abs(r['frac_by_wall'] - 0.7539) < 5e-4 and abs(r['frac_by_step'] - 0.7427) < 5e-4
+    assert abs(r['useful_frac_by_step'] - 17.11e6 * 6483264 / 1e12 / 157.3) < 1e-12 and abs(r['useful_frac_by_step'] - 0.7052) < 5e-4
+    assert list(r)[:8] == ['bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'useful_frac_by_step', 'frac_by_step']
+    assert r['launches_in_flight'] > 1 and r['avg_launch_ms'] == 0.11845 and 'median of 40 launches' in r['how']
+    # no uncaptured round to put events around: the wall time per launch stands in, and the record says so
+    r2 = bench.net_roofline(2048, None, 0.10429, 0.11196, 0.11365, 17.11e6)
+    assert r2['frac'] == r2['frac_by_wall'] and r2['avg_launch_ms'] == 0.11196 and 'wall time' in r2['how']

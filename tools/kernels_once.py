@@ -56,5 +56,27 @@ if what in ('all', 'free'):         # the free-running stepped path on PLAIN lau
     torch.cuda.synchronize()
     print('free-running: counters', run.counters())
     run.close()
+if what == 'pipe':           # tools/pmc_pipeline.sh: the evaluator inside the running free-running pipeline, then the same launches alone
+    m = ResidualCNN(); m.load_weights('tests/golden/good_model.h5')
+    run = sp.SelfPlayRun(m, n_games=4096 * 8, sims=400, seed=bench.SEED, max_slots=4096, keep_records=False, use_graph=False, stagger_span=6)
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 900
+    parts = run.b.parts
+    done = 0
+    while done < rounds:                 # the two half-batches' rounds handed to their streams alternately, 25 at a time (PipelinedSelfPlay.play_ply)
+        for b, s_ in zip(parts, run.b.streams):
+            with torch.cuda.stream(s_):
+                b.play_steps(25)
+        done += 25
+    torch.cuda.synchronize()
+    p0 = parts[0]
+    req, moves = p0._req.clone(), p0._moves.clone()
+    packed = m._ensure_packed()
+    pk = torch.empty((req.shape[0], _lib.REQUEST_MOVES), dtype=torch.float64, device='cuda'); v = torch.empty(req.shape[0], dtype=torch.float32, device='cuda')
+    print('pipeline: counters', run.counters(), 'asked rows in the burst batch', int((req.view(torch.int32)[:, 8] != 0).sum()))
+    run.close()
+    torch.cuda.synchronize()
+    for _ in range(60):
+        L.ccsp_net_forward_requests(packed.data_ptr(), req.data_ptr(), moves.data_ptr(), req.shape[0], pk.data_ptr(), v.data_ptr(), st)
+    torch.cuda.synchronize()
 if what == 'stepped':            # hipGraph replays: NOT under --pmc (the counter passes never finished with it)
     print(sp.bench_net_plies(4096, 400, plies=1))
