@@ -446,12 +446,18 @@ def config5(args, torch, rank, world, local, dist):
     # the training step's lazy initialisation (MIOpen kernel choice / build: ~5 s on a fresh box, where the driver runs this; well under a
     # second with a warm cache) is taken OUT of the iteration and reported on its own, so that train_s is what every later iteration pays
     t_w = time.time()
+
+    def progress(*a):                       # the loop's phase messages, with the time since config 5 began (stderr: the line on stdout stays alone)
+        sys.stderr.write('bench.py config 5 [%6.1f s] %s\n' % (time.time() - t_w, ' '.join(str(x) for x in a)))
+        sys.stderr.flush()
     warm = train.warm_up(device='cuda:%d' % local)
+    if rank == 0:
+        progress('training step warmed up on every rank')
     try:
         t0 = time.time()
         cur, best, it = train.evolve(w, best_model=w, iterations=1, num_self_play=args.config5_games, eval_games=24,
                                      sims=args.config5_sims, seed=SEED, data_dir=os.path.join(work, 'data'),
-                                     weights_dir=os.path.join(work, 'weights'), log=lambda *a: None, dist=dist, device=local,
+                                     weights_dir=os.path.join(work, 'weights'), log=progress, dist=dist, device=local,
                                      timings=timings)
         wall = time.time() - t0
     finally:
@@ -476,7 +482,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
     ap.add_argument('--sims', type=int, default=400)
-    ap.add_argument('--spread-plies', type=int, default=72, help='untimed plies before the warm-up: the first cohort of games spreads out')
+    # 160: the slots' first games begin spread over 148 steps, so that by the timed window games of EVERY length end at their long-run rates --
+    # a game discarded for no progress lasts 110-250 plies (80-190 steps), and with the 72 of round 5 the first cohort's were still in flight:
+    # discard rate of a 20-step window 0.131 / 0.156 / 0.177 / 0.177 at 72 / 120 / 160 / 200 against 0.19 of whole runs (profiles/r6_spread_sweep.txt);
+    # node-expansions/s do not depend on it (+- 0.5 %)
+    ap.add_argument('--spread-plies', type=int, default=160, help='untimed plies before the warm-up: the first cohort of games spreads out')
     ap.add_argument('--harvest-every', type=int, default=2)
     ap.add_argument('--min-seconds', type=float, default=1.0, help='shortest timed region: K more steps are added until it is reached')
     ap.add_argument('--fused-plies', type=int, default=192, help='variant 2a: timed plies of the fused kernel')

@@ -290,7 +290,7 @@ __device__ __forceinline__ uint16_t *blk_mv(uint8_t *b, int k) { return reinterp
 
 // Experiment switch (round 6): CCSP_TREE_NT = 1 gives the free-running path's block WRITES (wave_expand_answer,
 // wave_copy_block) a streaming cache policy, 2 also the old tree's reads of wave_copy_block and the selection's edge loads -- to see whether
-// the tree waves' traffic costs the evaluator beside them its weights in L2.  Default 0: measured, no gain (profiles/r6_tree_nt_ab.txt).
+// the tree waves' traffic costs the evaluator beside them its weights in L2.  Default 0: measured, no gain (profiles/r6_pipeline_ab.txt).
 #ifndef CCSP_TREE_NT
 #define CCSP_TREE_NT 0
 #endif
@@ -2072,6 +2072,10 @@ __global__ __launch_bounds__(64, CCSP_ADVANCE_WAVES) void advance_kernel(AdvArgs
                 ADV_LAP(t_sel);
                 load_engine_lines(&lds.T, lane_id_here());
                 __syncthreads();
+#ifdef CCSP_EXP_MOVEGEN_TWICE       // experiment (round 6): what the request's move list costs the pipeline -- generated twice, results unchanged
+                (void)wave_request_moves<true>(lds, leaf, leaf_player, A.moves + (size_t)g * REQ_MV);
+                __syncthreads();
+#endif
                 req_k = (uint32_t)wave_request_moves<true>(lds, leaf, leaf_player, A.moves + (size_t)g * REQ_MV);
                 if (lane_id_here() == 0) {
                     ulonglong2 *q = reinterpret_cast<ulonglong2 *>(A.req + g), *own = reinterpret_cast<ulonglong2 *>(P.pend + g);

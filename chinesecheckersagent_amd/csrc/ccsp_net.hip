@@ -682,6 +682,9 @@ __global__ __launch_bounds__(C::NTH) void net_forward_kernel(const float *__rest
             }
         }
     }
+#ifdef CCSP_EXP_NET_INPUT_DELAY     // experiment (round 6): an input phase longer by ~N x 30 ns (what generating the move lists here would add)
+    __builtin_amdgcn_s_sleep(CCSP_EXP_NET_INPUT_DELAY);
+#endif
     __syncthreads();
     NET_STAMP(0);
 #ifdef CCSP_STAMPS

@@ -30,14 +30,30 @@ constexpr int MG_SLOT = 24;                                 // bytes of LDS per 
 constexpr int MG_LIST_STATE = 6 * MG_SLOT + MG_LIST_PAD;     // bytes of list staging per position
 #define LST(L, s, c, i) (L).lists[(s) * MG_LIST_STATE + (c) * MG_SLOT + (i)]
 
-struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS: 7.1 KB -> five 4-wave workgroups per CU
+#ifndef MG_REGSTACK
+#define MG_REGSTACK 1          // 1: a lane's depth-first stack lives in a 64-bit register (6 bits per cell, <= 10 entries) instead of LDS (0: the LDS stacks of rounds 2-5; A/B profiles/r6_movegen_ab.txt)
+#endif
+constexpr int MG_REGROOM = 10;
+#ifndef MG_ORIGIN_FIRST
+#define MG_ORIGIN_FIRST 0      // (needs MG_REGSTACK) 1: the ORIGIN's six hop look-ups are made in the walk phase -- every lane busy, no visited
+#endif                         // test, the three patterns already in registers -- and left as the task's initial stack; only checkers that
+                               // can hop at all enter the search loop, those with two or more first hops before those with one
+static_assert(!MG_ORIGIN_FIRST || MG_REGSTACK, "MG_ORIGIN_FIRST keeps the initial stack as a register image");
+
+struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS: 7.1 KB -> five 4-wave workgroups per CU (5.9 KB -> six with MG_REGSTACK)
     uint8_t lines[MG_CHUNK][MG_LINES_STRIDE];               // 27 line patterns per state (+ pad)
     uint8_t lists[MG_CHUNK * MG_LIST_STATE];
     uint8_t cnt[MG_CHUNK][8];
+#if !MG_REGSTACK
     uint8_t stack[64][MG_STACK];                            // one depth-first stack per lane
-    uint8_t big[MG_BIGSTACK];
+#endif
+#if MG_ORIGIN_FIRST
+    uint8_t wl[MG_TASKS];                                   // the tasks that enter the search loop: >= 2 first hops from the front, 1 from the back
+#endif
+    uint8_t big[MG_BIGSTACK];                               // (also the PACKED write-out's 32 x u16 list offsets, once the searches are done)
     uint32_t redo[MG_TASKS / 32];                           // tasks to redo on the big stack (bit per task)
 };
+static_assert(MG_BIGSTACK >= 2 * MG_CHUNK, "the packed write-out keeps 32 x u16 in `big`");
 
 
 // B2-B4 over an array of positions.  The ordered hop search of one checker (board.py:166-211) is a serial
@@ -46,8 +62,10 @@ struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS
 // (one visited cell per iteration: six mirror-hop lookups HOP[line pattern][position][sense], ccsp_rules.h, and a
 // stack in LDS) and pulls the next task
 // of the chunk the moment its own is finished (ballot + rank) -- no lane waits for the longest walk of its wave.
-// Hop landings stay on the origin's sub-lattice (row and column keep their parity: <= 4 x 4 cells), so the visited
-// set is 16 bits indexed by (row / 2, column / 2) -- 32-bit tests instead of 64-bit shifts on a cell mask.
+// Hop landings stay on the origin's sub-lattice (row and column keep their parity: <= 4 x 4 cells), so every cell a search
+// sees has the parity of the origin's cell index (7 r + c = r + c mod 2) and cell >> 1 names it uniquely: the visited set is
+// 25 bits indexed by cell >> 1 -- one shift per test, no 64-bit shifts on a cell mask, no (row / 2, column / 2) arithmetic
+// (round 6; the 16-bit sub-lattice index cost two multiply-adds and a mask per hop direction).
 // Per-checker lists are staged in LDS and written out in the reference's move order, a position at a time,
 // neighbouring lanes writing neighbouring bytes.
 // GREEDY (next-4): the same search, but what is written out is GreedyPlayer.decide_move(training=True)
@@ -96,7 +114,11 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     // through the origin (bits beyond a line's end are preset; the byte is stored unconditionally, kept only if legal).  Done here,
     // with every lane busy, instead of inside the search loop, where the lanes reach their origins at different iterations and the
     // whole wave would step through these ~90 instructions every time one of them does.
-    for (int t = lane; t < ntasks; t += 64) {
+    int n_two = 0, n_one = 0;                           // MG_ORIGIN_FIRST: tasks with >= 2 / exactly 1 first hop (wave-uniform)
+    for (int t0 = 0; t0 < ntasks; t0 += 64) {
+        const int t = t0 + lane;
+        int hops0 = 0;                                  // first hops of this lane's task
+        if (t < ntasks) {
         const int s = (int)(__umul24((unsigned)t, 171u) >> 10), c = t - 6 * s;      // t / 6, exact for t < 515
         const int x = LST(L, s, c, MG_SLOT - 1);
         const int r = (int)(__umul24((unsigned)x, 37u) >> 8), col = x - 7 * r, m = r < col ? r : col;
@@ -108,6 +130,41 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         MG_WALK(p0, r, -1, -7) MG_WALK(p1, col, 1, 1) MG_WALK(p2, m, 1, 8) MG_WALK(p0, r, 1, 7) MG_WALK(p1, col, -1, -1) MG_WALK(p2, m, -1, -8)
 #undef MG_WALK
         L.cnt[s][c] = (uint8_t)k;
+#if MG_ORIGIN_FIRST
+        // the origin's own hops (the visit the search would begin with): the checker lifted off its three lines (board.py:158), both senses of
+        // each line in one 16-bit read, the landings ranked NW, W, S, SE, E, N into the register image of the stack (N on top); nothing is
+        // visited yet but the origin, which no hop lands on.  The image, the count, the origin and the walk count go into bytes 8..15 of the
+        // task's list slot (free until the list has eight entries, by which time the task has long read them).
+        {
+            const uint32_t q0 = p0 & ~(1u << r), q1 = p1 & ~(1u << col), q2 = p2 & ~(1u << m);
+            const uint32_t h0 = *reinterpret_cast<const uint16_t *>(&T.hop[q0][r][0]);
+            const uint32_t h1 = *reinterpret_cast<const uint16_t *>(&T.hop[q1][col][0]);
+            const uint32_t h2 = *reinterpret_cast<const uint16_t *>(&T.hop[q2][m][0]);
+            const int b0 = x - 7 * r, b1 = x - col, b2 = x - 8 * m;
+            uint32_t accA = 0, accB = 0; int nA = 0, nB = 0;
+#define MG_ACC0(ACC, N, HP, BASE, STRIDE) { const int hp = (int)(HP); const bool ok = hp < 7; \
+                                            ACC = ok ? ((ACC << 6) | (uint32_t)(hp * (STRIDE) + (BASE))) : ACC; N += ok ? 1 : 0; }
+            MG_ACC0(accA, nA, h2 & 0xFF, b2, 8)      // NW
+            MG_ACC0(accA, nA, h1 & 0xFF, b1, 1)      // W
+            MG_ACC0(accA, nA, h0 >> 8, b0, 7)        // S
+            MG_ACC0(accB, nB, h2 >> 8, b2, 8)        // SE
+            MG_ACC0(accB, nB, h1 >> 8, b1, 1)        // E
+            MG_ACC0(accB, nB, h0 & 0xFF, b0, 7)      // N
+#undef MG_ACC0
+            hops0 = nA + nB;
+            const uint64_t image = (((uint64_t)accA << (6 * nB)) | (uint64_t)accB) | ((uint64_t)x << 36) | ((uint64_t)k << 44) | ((uint64_t)hops0 << 48);
+            *reinterpret_cast<uint64_t *>(&LST(L, s, c, 8)) = image;
+        }
+#endif
+        }
+#if MG_ORIGIN_FIRST
+        // the worklist: tasks with two or more first hops from the front, with exactly one from the back -- the long searches start first
+        // (a wave is done when its last lane is), checkers that cannot hop never enter the loop
+        const uint64_t two = __ballot(hops0 >= 2), one = __ballot(hops0 == 1), below = (1ULL << lane) - 1;
+        if (hops0 >= 2) L.wl[n_two + __popcll(two & below)] = (uint8_t)t;
+        if (hops0 == 1) L.wl[MG_TASKS - 1 - (n_one + __popcll(one & below))] = (uint8_t)t;
+        n_two += __popcll(two); n_one += __popcll(one);
+#endif
     }
     __syncthreads();
 
@@ -120,57 +177,154 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     int task = lane;                                    // current task (position-major: task = 6 * s + c)
     int next = 64;                                      // next unassigned task of the chunk (wave-uniform)
     int st_s = 0, st_c = 0, origin = 0, cnt_n = 0, sp = 0, orow = 0, oc = 0;
-    uint32_t visited = 0;                               // sub-lattice cells seen: bit (row / 2) * 4 + column / 2
+    uint32_t visited = 0;                               // cells seen: bit cell >> 1 (all of one parity, see above)
+    const uint8_t *pat = L.lines[0];                    // the task's position: its 27 line patterns ...
+    uint8_t *lst = &LST(L, 0, 0, 0);                    // ... and the task's list (both set once per task, not per visited cell)
+    uint32_t lift0 = ~0u, lift1 = ~0u, lift2 = ~0u;     // the moving checker lifted off its three lines (board.py:158): pattern masks, per task
+    int odiag = 0;                                      // orow - oc: names the origin's diagonal
     bool active = false;
 
     // a task starts with its origin on the stack, its list holding the walks
     auto start_task = [&](int t, uint8_t *stk) {
         st_s = (int)(__umul24((unsigned)t, 171u) >> 10);                   // t / 6, exact for t < 515 (tasks: < 192)
         st_c = t - 6 * st_s;
-        origin = LST(L, st_s, st_c, MG_SLOT - 1);
+        pat = L.lines[st_s];
+        lst = &LST(L, st_s, st_c, 0);
+        origin = lst[MG_SLOT - 1];
         cnt_n = L.cnt[st_s][st_c]; visited = 0;
         orow = (int)(__umul24((unsigned)origin, 37u) >> 8); oc = origin - 7 * orow;
-        stk[0] = (uint8_t)origin; sp = 1;
+        lift0 = ~(1u << orow); lift1 = ~(1u << oc); lift2 = ~(1u << (orow < oc ? orow : oc)); odiag = orow - oc;
+        if (stk != nullptr) stk[0] = (uint8_t)origin;
+        sp = 1;
     };
     // one pop; returns false when the visit would not fit the stack (`room` entries): nothing is changed then
     auto step = [&](uint8_t *stk, int room) -> bool {
         const int x = stk[sp - 1];
         const int r = (int)(__umul24((unsigned)x, 37u) >> 8), c = x - 7 * r;
-        const int xi = (r >> 1) * 4 + (c >> 1);
+        const int xi = x >> 1;
         if ((visited >> xi) & 1u) { sp--; return true; }
         if (sp - 1 + 6 > room) return false;                           // six tentative pushes must fit
         sp--;
         visited |= 1u << xi;
-        const uint8_t *pat = L.lines[st_s];
         // the three lines through x; the moving checker is lifted off its own lines (board.py:158)
         uint32_t p0 = pat[c], p1 = pat[7 + r], p2 = pat[20 + r - c];
-        const int m = r < c ? r : c, om = orow < oc ? orow : oc;
-        if (c == oc) p0 &= ~(1u << orow);
-        if (r == orow) p1 &= ~(1u << oc);
-        if (r - c == orow - oc) p2 &= ~(1u << om);
-        LST(L, st_s, st_c, cnt_n) = (uint8_t)x;                        // a hop landing (the byte stored for the origin itself, which is
+        const int m = r < c ? r : c;
+        if (c == oc) p0 &= lift0;
+        if (r == orow) p1 &= lift1;
+        if (r - c == odiag) p2 &= lift2;
+        lst[cnt_n] = (uint8_t)x;                                       // a hop landing (the byte stored for the origin itself, which is
         cnt_n += x != origin ? 1 : 0;                                   // not a move, is overwritten by the next landing)
         // both senses of a line in one 16-bit read: low byte = sense -, high byte = sense +
         const uint32_t h0 = *reinterpret_cast<const uint16_t *>(&T.hop[p0][r][0]);
         const uint32_t h1 = *reinterpret_cast<const uint16_t *>(&T.hop[p1][c][0]);
         const uint32_t h2 = *reinterpret_cast<const uint16_t *>(&T.hop[p2][m][0]);
-        const int rh = r >> 1, ch = c >> 1;
         // directions N,E,SE,S,W,NW = (axis 0,-) (1,+) (2,+) (0,+) (1,-) (2,-); pushed in reverse order (the byte is
         // stored unconditionally and kept only if the landing is legal and unvisited: no branches).
-        // landing of a hop to line position hp: cell x + (hp - pos) * stride; sub-lattice index from its row / column (a diagonal
-        // hop of 2 h cells moves the index by 4 h + h)
-#define MG_PUSH(HP, POS, STRIDE, IDX) { const int hp = (int)(HP); const int land = x + (hp - (POS)) * (STRIDE); \
-                                        stk[sp] = (uint8_t)land; sp += ((hp < 7) & (((visited >> ((IDX) & 15)) & 1u) == 0)) ? 1 : 0; }
-        MG_PUSH(h2 & 0xFF, m, 8, xi + 5 * ((hp - m) >> 1))      // NW
-        MG_PUSH(h1 & 0xFF, c, 1, rh * 4 + (hp >> 1))                                 // W
-        MG_PUSH(h0 >> 8, r, 7, (hp >> 1) * 4 + ch)                                   // S
-        MG_PUSH(h2 >> 8, m, 8, xi + 5 * ((hp - m) >> 1))        // SE
-        MG_PUSH(h1 >> 8, c, 1, rh * 4 + (hp >> 1))                                   // E
-        MG_PUSH(h0 & 0xFF, r, 7, (hp >> 1) * 4 + ch)                                 // N
+        // landing of a hop to line position hp: cell x + (hp - pos) * stride = hp * stride + (x - pos * stride)
+        const int b0 = x - 7 * r, b1 = x - c, b2 = x - 8 * m;
+#define MG_PUSH(HP, BASE, STRIDE) { const int hp = (int)(HP); const int land = hp * (STRIDE) + (BASE); \
+                                    stk[sp] = (uint8_t)land; sp += ((hp < 7) & (__builtin_amdgcn_ubfe(visited, (unsigned)land >> 1, 1u) == 0)) ? 1 : 0; }
+        MG_PUSH(h2 & 0xFF, b2, 8)      // NW
+        MG_PUSH(h1 & 0xFF, b1, 1)      // W
+        MG_PUSH(h0 >> 8, b0, 7)        // S
+        MG_PUSH(h2 >> 8, b2, 8)        // SE
+        MG_PUSH(h1 >> 8, b1, 1)        // E
+        MG_PUSH(h0 & 0xFF, b0, 7)      // N
 #undef MG_PUSH
         return true;
     };
     auto finish_task = [&]() { L.cnt[st_s][st_c] = (uint8_t)cnt_n; };
+#if MG_REGSTACK
+    // The same pop with the lane's stack in a REGISTER: rs = cells of 6 bits, the top in the low bits.  The six landings are ranked into two
+    // 18-bit accumulators (NW, W, S | SE, E, N: first pushed = highest) and shifted in behind the popped cell in one go; the visit is
+    // refused -- nothing changed -- when the stack would exceed `room` (<= 10) entries: the big-stack redo path below, as before.
+    // Takes one LDS read (the top) and six byte-wide LDS writes off every visited cell's dependent chain, and the stacks' 1280 bytes
+    // off the wave's LDS (six workgroups per CU instead of five).
+    uint64_t rs = 0;
+    uint8_t *const stk = nullptr;                                    // (no LDS stack: start_task leaves the origin to `rs`)
+    auto step_reg = [&](int room) -> bool {
+        const int x = (int)((uint32_t)rs & 63u);
+        const int xi = x >> 1;
+        if ((visited >> xi) & 1u) { rs >>= 6; sp--; return true; }
+        const int r = (int)(__umul24((unsigned)x, 37u) >> 8), c = x - 7 * r;
+        uint32_t p0 = pat[c], p1 = pat[7 + r], p2 = pat[20 + r - c];
+        const int m = r < c ? r : c;
+        if (c == oc) p0 &= lift0;
+        if (r == orow) p1 &= lift1;
+        if (r - c == odiag) p2 &= lift2;
+        const uint32_t h0 = *reinterpret_cast<const uint16_t *>(&T.hop[p0][r][0]);
+        const uint32_t h1 = *reinterpret_cast<const uint16_t *>(&T.hop[p1][c][0]);
+        const uint32_t h2 = *reinterpret_cast<const uint16_t *>(&T.hop[p2][m][0]);
+        const int b0 = x - 7 * r, b1 = x - c, b2 = x - 8 * m;
+        const uint32_t seen = visited | (1u << xi);
+        uint32_t accA = 0, accB = 0; int nA = 0, nB = 0;
+#define MG_ACC(ACC, N, HP, BASE, STRIDE) { const int hp = (int)(HP); const int land = hp * (STRIDE) + (BASE); \
+                                           const bool ok = (hp < 7) & (__builtin_amdgcn_ubfe(seen, (unsigned)land >> 1, 1u) == 0); \
+                                           ACC = ok ? ((ACC << 6) | (uint32_t)land) : ACC; N += ok ? 1 : 0; }
+        MG_ACC(accA, nA, h2 & 0xFF, b2, 8)      // NW
+        MG_ACC(accA, nA, h1 & 0xFF, b1, 1)      // W
+        MG_ACC(accA, nA, h0 >> 8, b0, 7)        // S
+        MG_ACC(accB, nB, h2 >> 8, b2, 8)        // SE
+        MG_ACC(accB, nB, h1 >> 8, b1, 1)        // E
+        MG_ACC(accB, nB, h0 & 0xFF, b0, 7)      // N
+#undef MG_ACC
+        if (sp - 1 + nA + nB > room) return false;
+        visited = seen;
+        lst[cnt_n] = (uint8_t)x;
+        cnt_n += x != origin ? 1 : 0;
+        rs >>= 6;
+        rs = (rs << (6 * nA)) | (uint64_t)accA;
+        rs = (rs << (6 * nB)) | (uint64_t)accB;
+        sp += nA + nB - 1;
+        return true;
+    };
+    const int room = cap < MG_REGROOM ? cap : MG_REGROOM;
+#if MG_ORIGIN_FIRST
+    const int nwork = n_two + n_one;                                 // entries of the worklist
+    auto work_at = [&](int i) -> int { return (int)L.wl[i < n_two ? i : MG_TASKS - 1 - (i - n_two)]; };
+    // a task starts behind its origin's visit: the stack image the walk phase left, the origin marked, the list holding the walks
+    auto start_work = [&](int t) {
+        st_s = (int)(__umul24((unsigned)t, 171u) >> 10);
+        st_c = t - 6 * st_s;
+        pat = L.lines[st_s];
+        lst = &LST(L, st_s, st_c, 0);
+        const uint64_t image = *reinterpret_cast<const uint64_t *>(lst + 8);
+        rs = image & ((1ULL << 36) - 1);
+        origin = (int)((image >> 36) & 63); cnt_n = (int)((image >> 44) & 15); sp = (int)((image >> 48) & 7);
+        visited = 1u << (origin >> 1);
+        orow = (int)(__umul24((unsigned)origin, 37u) >> 8); oc = origin - 7 * orow;
+        lift0 = ~(1u << orow); lift1 = ~(1u << oc); lift2 = ~(1u << (orow < oc ? orow : oc)); odiag = orow - oc;
+    };
+    if (lane < nwork) { task = work_at(lane); start_work(task); active = true; }
+#define MG_NTASKS_IN_LOOP nwork
+#define MG_START(i) { task = work_at(i); start_work(task); }
+#else
+    if (task < ntasks) { start_task(task, stk); rs = (uint64_t)origin; active = true; }
+#define MG_NTASKS_IN_LOOP ntasks
+#define MG_START(i) { task = (i); start_task(task, stk); rs = (uint64_t)origin; }
+#endif
+
+    while (__any(active)) {
+        if (active) {
+            if (!step_reg(room)) {
+                atomicOr(&L.redo[task >> 5], 1u << (task & 31));
+                active = false;
+            } else if (sp == 0) {
+                finish_task();
+                active = false;
+            }
+        }
+        const uint64_t idle = __ballot(!active);
+        if (next < MG_NTASKS_IN_LOOP && idle) {
+            const int rank = __popcll(idle & ((1ULL << lane) - 1));
+            const int i = next + rank;
+            if (!active && i < MG_NTASKS_IN_LOOP) { MG_START(i) active = true; }
+            next += __popcll(idle);
+        }
+    }
+#undef MG_NTASKS_IN_LOOP
+#undef MG_START
+#else
     uint8_t *stk = L.stack[lane];
     if (task < ntasks) { start_task(task, stk); active = true; }
 
@@ -193,6 +347,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
             next += __popcll(idle);
         }
     }
+#endif
     // searches that did not fit a lane's stack: one at a time, lane 0, on the wave's big stack
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -238,7 +393,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         int incl = k;
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) { const int o = __shfl_up(incl, d); if ((lane & 31) >= d) incl += o; }
-        if (lane < MG_CHUNK) reinterpret_cast<uint16_t *>(L.stack)[lane] = (uint16_t)(incl - k);      // (the stacks are free by now)
+        if (lane < MG_CHUNK) reinterpret_cast<uint16_t *>(L.big)[lane] = (uint16_t)(incl - k);      // (the big stack is free by now)
     }
     __syncthreads();
     const int half = lane >> 5, hl = lane & 31;
@@ -257,7 +412,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
             for (int j = hl; j < K; j += 32) {
                 int id, dest;
                 move_at(j, id, dest);
-                const long long row = PACKED ? base * CCSP_MAX_MOVES + reinterpret_cast<const uint16_t *>(L.stack)[on ? s : 0]
+                const long long row = PACKED ? base * CCSP_MAX_MOVES + reinterpret_cast<const uint16_t *>(L.big)[on ? s : 0]
                                              : (base + s) * CCSP_MAX_MOVES;
                 reinterpret_cast<uint16_t *>(moves)[row + j] = (uint16_t)id | ((uint16_t)dest << 8);
             }

@@ -662,6 +662,19 @@ class GameStore(object):
 
 
 MAX_SLOTS = 4096          # concurrent games per GPU (BASELINE.json); more games than this restart in the slots that come free
+MIN_GAMES_PER_RANK = 256  # a cohort smaller than this per rank is LATENCY-bound (a round's length does not depend on how many slots it
+                          # carries: one slot, 23 or 180 take the same time per step), so spreading it over more GPUs buys nothing:
+                          # config 5's real cohort (config.py:57-58: 180 games per iteration) at 800 simulations takes 6.52 s in 180 slots
+                          # of ONE GPU and 5.91 s as eight ranks' shares of 23 -- 1.10 x for 8 x the GPUs (profiles/r6_small_cohort.txt).
+
+
+def selfplay_ranks(n_games, world, min_games_per_rank=None):
+    """ranks that PLAY a cohort of n_games when `world` are there: min(world, ceil(n_games / MIN_GAMES_PER_RANK)) -- rank r below that
+    number plays ids r, r + ranks, ...; the others sit the self-play out (and join whatever comes after it: the DDP fit, the arena).
+    A game's record depends on its id alone, so the rows are the same whatever the number."""
+    m = MIN_GAMES_PER_RANK if min_games_per_rank is None else max(1, int(min_games_per_rank))
+    return max(1, min(int(world), (int(n_games) + m - 1) // m))
+
 HARVEST_EVERY = 2         # steps between two harvests of the sample log (a harvest costs the run 0.3 % at 8 and no more at 2; the
                           # shorter the interval, the less is left to convert when a run ends: at the end of a 20-step region 22 ms
                           # against 37-51 ms with 4 -- +0.5-1 % of node-expansions/s over such a region, measured in round 5)
@@ -957,7 +970,7 @@ def generate_self_play(worker_id, model_path, num_self_play, model2_path=None, s
 
 def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model2_path=None, sims=MCTS_SIMULATIONS, seed=None,
                                    first_game=None, randomised=False, devices=None, as_arrays=False, out_dir=None, max_slots=MAX_SLOTS,
-                                   return_summary=False, timeout=None, max_steps=None, with_games=False):
+                                   return_summary=False, timeout=None, max_steps=None, with_games=False, min_games_per_rank=None):
     """train.generate_self_play_in_parallel (train.py:71-105) with GPUs for workers: `num_workers` rank processes, one per
     MI355X (devices[r], default r), are started from THIS process -- which never touches the GPU -- and play the ids
     first_game + j, j < num_self_play, sharded j mod num_workers; their counters and visit histograms meet in one RCCL
@@ -966,6 +979,8 @@ def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model
     with return_summary=True also the all-reduced summary {'counters': ..., 'visit_histogram': ...}.
     timeout (seconds): ranks still running after it are terminated (then killed) and the call raises, instead of waiting for ever on
     a rank that stalls in a collective or a wedged kernel.
+    min_games_per_rank (default MIN_GAMES_PER_RANK = 256): fewer rank processes are started for a small cohort -- selfplay_ranks(): a batch
+    that does not fill a GPU is latency-bound, more GPUs do not shorten it; the summary's `world` says how many played.
     max_steps: every rank stops after that many steps (of sims + 1 rounds of all its slots) and hands back the games that have ENDED by
     then -- a bounded rehearsal of a shape too long to play out (BASELINE config 4 on one device); with_games (as_arrays): the game id of
     every row as a fourth array."""
@@ -978,6 +993,9 @@ def generate_self_play_in_parallel(model_path, num_self_play, num_workers, model
         first_game = _next_game[0]
         _next_game[0] += num_self_play
     seed = _default_seed[0] if seed is None else seed
+    num_workers = selfplay_ranks(num_self_play, num_workers, min_games_per_rank)          # (small cohorts: fewer ranks, the same games)
+    if devices is not None:
+        devices = list(devices)[:num_workers]
     tmp = None
     if out_dir is None:
         tmp = tempfile.TemporaryDirectory(prefix='ccsp-selfplay-')

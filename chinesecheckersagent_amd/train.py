@@ -459,18 +459,21 @@ def evaluate(best_model, cur_model, num_games=EVAL_GAMES, sims=None, seed=None, 
     return w_cur
 
 
-def _selfplay_shard(p1, p2, num_self_play, sims, seed, game0, dist, device, data_dir, iteration_count):
+def _selfplay_shard(p1, p2, num_self_play, sims, seed, game0, dist, device, data_dir, iteration_count, min_games_per_rank=None):
     """this rank's share of an iteration's self-play games -> the iteration's (board_x, pi_y, v_y) on EVERY rank, rows in
     game-id order (what one GPU playing all the games would return), plus (games kept, games played, expansions)."""
     import torch
     from . import selfplay as sp
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
-    m1, m2 = sp._load_models(p1, p2, device='cuda:%d' % device)
-    mine = len(range(rank, num_self_play, world))
+    # a small cohort is latency-bound: min(world, ceil(games / 256)) ranks play it (selfplay.selfplay_ranks), the others wait at the
+    # all-reduce below and join the fit and the arena -- config 5's real 180 games: one rank (profiles/r6_small_cohort.txt)
+    active = sp.selfplay_ranks(num_self_play, world, min_games_per_rank)
+    mine = len(range(rank, num_self_play, active)) if rank < active else 0
     sink = sp.TrainDataSink()
     kept = played = expansions = 0
     if mine > 0:
-        run = sp.SelfPlayRun(m1, m2, n_games=mine, sims=sims, seed=seed, first_game=game0 + rank, game_stride=world, device=device,
+        m1, m2 = sp._load_models(p1, p2, device='cuda:%d' % device)
+        run = sp.SelfPlayRun(m1, m2, n_games=mine, sims=sims, seed=seed, first_game=game0 + rank, game_stride=active, device=device,
                              keep_records=False, sink=sink)
         try:
             run.run()
@@ -511,7 +514,7 @@ def _selfplay_shard(p1, p2, num_self_play, sims, seed, game0, dist, device, data
 
 def evolve(cur_model_path, other_opponent_for_selfplay=None, iteration_count=0, best_model=None, iterations=None,
            num_self_play=NUM_SELF_PLAY, eval_games=EVAL_GAMES, sims=None, seed=None, data_dir=None, weights_dir=SAVE_WEIGHTS_DIR,
-           log=print, dist=None, device=0, timings=None):
+           log=print, dist=None, device=0, timings=None, selfplay_min_games_per_rank=None):
     """train.evolve (train.py:235-317): self-play -> convert / augment / save -> pool with the previous iteration ->
     train -> (if a best model is tracked) gate the new weights on more than int(0.55 * eval_games) wins.
     The reference loops forever; `iterations` bounds it (None = forever).
@@ -521,12 +524,14 @@ def evolve(cur_model_path, other_opponent_for_selfplay=None, iteration_count=0, 
     (launch.init_rank; `python -m chinesecheckersagent_amd.train --gpus N` starts the ranks): rank r plays the self-play
     games r, r + N, ... and the arena games r, r + N, ..., the ranks' rows are merged in game-id order (the SAME arrays a
     single GPU produces), the fit runs under DistributedDataParallel with each rank's share of every batch, and the gate's win
-    counts are all-reduced -- every rank takes the same decision.  Rank 0 writes the data and weight files.
+    counts are all-reduced -- every rank takes the same decision.  Rank 0 writes the data and weight files.  A cohort of fewer than
+    256 games per rank is played by fewer ranks (selfplay.selfplay_ranks; selfplay_min_games_per_rank overrides the 256): latency-bound.
     `timings` (a list) receives one dict of wall seconds per phase and iteration.
     Returns (cur_model_path, best_model, iteration_count)."""
     import time
     from . import utils
     from .config import MCTS_SIMULATIONS, SAVE_TRAIN_DATA_DIR
+    from .selfplay import selfplay_ranks as sp_ranks
     sims = MCTS_SIMULATIONS if sims is None else sims
     data_dir = SAVE_TRAIN_DATA_DIR if data_dir is None else data_dir
     rank = dist.get_rank() if dist is not None else 0
@@ -549,7 +554,9 @@ def evolve(cur_model_path, other_opponent_for_selfplay=None, iteration_count=0, 
         else:
             p1, p2 = cur_model_path, None
         board_x, pi_y, v_y, kept, played, expansions = _selfplay_shard(p1, p2, num_self_play, sims, seed, game0, dist, device,
-                                                                       data_dir, iteration_count)
+                                                                       data_dir, iteration_count, selfplay_min_games_per_rank)
+        if dist is not None:
+            tm['selfplay_ranks'] = sp_ranks(num_self_play, dist.get_world_size(), selfplay_min_games_per_rank)
         game0 += num_self_play
         tm['selfplay_s'] = time.time() - t0
         tm['selfplay_games'], tm['selfplay_games_kept'], tm['selfplay_expansions'] = played, kept, expansions
@@ -565,6 +572,7 @@ def evolve(cur_model_path, other_opponent_for_selfplay=None, iteration_count=0, 
         board_x, pi_y, v_y, used = combine_prev_iters_train_data(board_x, pi_y, v_y, iteration_count, directory=data_dir)
         tm['data_s'] = time.time() - t0
         tm['samples'] = int(len(v_y))
+        log('iteration %d: self-play %.1f s, data %.1f s, %d samples to fit' % (iteration_count, tm['selfplay_s'], tm['data_s'], tm['samples']))
         if used == 0:
             log('no training data for iteration %d, re-iterating' % iteration_count)
             done += 1
@@ -583,6 +591,7 @@ def evolve(cur_model_path, other_opponent_for_selfplay=None, iteration_count=0, 
         tm['train_capture_s'] = last_fit_timings.get('capture_s', 0.0)
         tm['train_epochs_s'] = last_fit_timings.get('epochs_s', 0.0)
         tm['train_steps'] = last_fit_timings.get('steps', 0)
+        log('iteration %d: fit %.1f s (%d steps, epochs %.1f s)' % (iteration_count, tm['train_s'], tm['train_steps'], tm['train_epochs_s']))
         # evaluate (train.py:308-314)
         if best_model is not None:
             t0 = time.time()

@@ -598,14 +598,21 @@ def test_generate_self_play_in_parallel_world2_on_one_device(golden_dir):
     from chinesecheckersagent_amd import selfplay as sp
     w = golden_dir + '/good_model.h5'
     n, sims, seed, first = 9, 8, 23, 500
-    par, summ = sp.generate_self_play_in_parallel(w, n, 2, sims=sims, seed=seed, first_game=first, devices=[0, 0], return_summary=True)
+    par, summ = sp.generate_self_play_in_parallel(w, n, 2, sims=sims, seed=seed, first_game=first, devices=[0, 0], return_summary=True,
+                                                  min_games_per_rank=1)
     one = sp.generate_self_play(1, w, n, sims=sims, seed=seed, first_game=first)
     assert _records(par) == _records(one) and len(one) > 0
+    # the default policy for a cohort this small (latency-bound: selfplay.selfplay_ranks, profiles/r6_small_cohort.txt): ONE rank plays it
+    # -- the same records, the summary says how many ranks played
+    assert sp.selfplay_ranks(9, 2) == 1 and sp.selfplay_ranks(180, 8) == 1 and sp.selfplay_ranks(257, 8) == 2 and sp.selfplay_ranks(32768, 8) == 8
+    par1, summ1 = sp.generate_self_play_in_parallel(w, n, 2, sims=sims, seed=seed, first_game=first, devices=[0, 0], return_summary=True)
+    assert _records(par1) == _records(one) and summ1['world'] == 1 and summ1['counters']['expansions'] == summ['counters']['expansions']
     c = summ['counters']
     assert summ['world'] == 2 and summ['backend'] == 'gloo' and c['errors'] == 0
     assert c['games_won'] == len(one) and c['games_won'] + c['games_discarded'] == n
     assert sum(summ['visit_histogram']) == c['mcts_plies'] * sims
-    bx, py, vy = sp.generate_self_play_in_parallel(w, n, 2, sims=sims, seed=seed, first_game=first, devices=[0, 0], as_arrays=True)
+    bx, py, vy = sp.generate_self_play_in_parallel(w, n, 2, sims=sims, seed=seed, first_game=first, devices=[0, 0], as_arrays=True,
+                                                   min_games_per_rank=1)
     assert len(vy) == sum(len(h) for h, _ in one)
     from chinesecheckersagent_amd import utils
     wx, wp, wv = utils.convert_to_train_data(one)

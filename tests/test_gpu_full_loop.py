@@ -67,7 +67,9 @@ def test_evolve_world2_on_one_device_equals_world1(golden_dir, tmp_path):
     d1, d2 = tmp_path / 'one', tmp_path / 'two'
     t1 = []
     cur1, best1, it1 = tr.evolve(start, data_dir=str(d1 / 'data'), weights_dir=str(d1 / 'weights'), log=lambda *a: None, timings=t1, **kw)
-    cur2, best2, it2, t2 = tr.evolve_in_parallel(2, start, devices=[0, 0], data_dir=str(d2 / 'data'), weights_dir=str(d2 / 'weights'), **kw)
+    cur2, best2, it2, t2 = tr.evolve_in_parallel(2, start, devices=[0, 0], data_dir=str(d2 / 'data'), weights_dir=str(d2 / 'weights'),
+                                                 selfplay_min_games_per_rank=1, **kw)            # (both ranks play: the sharded path)
+    assert t2[0]['selfplay_ranks'] == 2
     assert it1 == it2 == 1 and os.path.basename(cur1) == os.path.basename(cur2) == 'version0000-weights.h5'
     f1, f2 = H5File(str(d1 / 'data' / 'data-for-iter-0.h5')), H5File(str(d2 / 'data' / 'data-for-iter-0.h5'))
     for name in ('board_x', 'pi_y', 'v_y'):
