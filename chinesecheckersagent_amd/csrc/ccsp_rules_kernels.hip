@@ -14,10 +14,8 @@ constexpr int MG_WAVES = MG_THREADS / 64;
 constexpr int MG_CHUNK = 32;                                // states per wave
 constexpr int MG_STATES = MG_WAVES * MG_CHUNK;              // 128 states per workgroup
 constexpr int MG_TASKS = MG_CHUNK * 6;                      // (state, checker) tasks per wave
-constexpr int MG_STACK = 20;                                // bytes of depth-first stack per lane: 5 dwords (an odd stride: the 64 stacks
-                                                            // spread over all banks).  Real positions never hold more than 8 entries
-                                                            // (tests/test_device_logic_on_host.py: 400 000 positions); a search that would
-                                                            // need more is redone on the wave's one big stack (MG_BIGSTACK)
+constexpr int MG_STACK = 20;                                // largest value of the test hook ccsp_debug_movegen_stack_cap (the LDS stacks of
+                                                            // rounds 2-5 held 20 entries; a lane's register stack holds MG_REGROOM)
 constexpr int MG_BIGSTACK = 96;                             // >= 81 (<= 5 pending siblings per visited sub-lattice cell (16) + 1) + 6 tentative
 constexpr int MG_SLOT = 24;                                 // bytes of LDS per checker list (<= 21 used)
 #ifndef MG_LINES_STRIDE
@@ -30,26 +28,17 @@ constexpr int MG_SLOT = 24;                                 // bytes of LDS per 
 constexpr int MG_LIST_STATE = 6 * MG_SLOT + MG_LIST_PAD;     // bytes of list staging per position
 #define LST(L, s, c, i) (L).lists[(s) * MG_LIST_STATE + (c) * MG_SLOT + (i)]
 
-#ifndef MG_REGSTACK
-#define MG_REGSTACK 1          // 1: a lane's depth-first stack lives in a 64-bit register (6 bits per cell, <= 10 entries) instead of LDS (0: the LDS stacks of rounds 2-5; A/B profiles/r6_movegen_ab.txt)
-#endif
-constexpr int MG_REGROOM = 10;
-#ifndef MG_ORIGIN_FIRST
-#define MG_ORIGIN_FIRST 0      // (needs MG_REGSTACK) 1: the ORIGIN's six hop look-ups are made in the walk phase -- every lane busy, no visited
-#endif                         // test, the three patterns already in registers -- and left as the task's initial stack; only checkers that
-                               // can hop at all enter the search loop, those with two or more first hops before those with one
-static_assert(!MG_ORIGIN_FIRST || MG_REGSTACK, "MG_ORIGIN_FIRST keeps the initial stack as a register image");
+constexpr int MG_REGROOM = 10;                              // entries of a lane's depth-first stack: 6 bits per cell in a 64-bit REGISTER (round 6).
+                                                            // Real positions never hold more than 8 (tests/test_device_logic_on_host.py:
+                                                            // 400 000 positions); a search that would need more is redone on the wave's one
+                                                            // big stack in LDS (MG_BIGSTACK)
 
-struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS: 7.1 KB -> five 4-wave workgroups per CU (5.9 KB -> six with MG_REGSTACK)
+struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS: 6.1 KB -> SIX 4-wave workgroups per CU (the per-lane LDS stacks of
+                                                                 // rounds 2-5 made it 7.1 KB and five)
     uint8_t lines[MG_CHUNK][MG_LINES_STRIDE];               // 27 line patterns per state (+ pad)
     uint8_t lists[MG_CHUNK * MG_LIST_STATE];
     uint8_t cnt[MG_CHUNK][8];
-#if !MG_REGSTACK
-    uint8_t stack[64][MG_STACK];                            // one depth-first stack per lane
-#endif
-#if MG_ORIGIN_FIRST
     uint8_t wl[MG_TASKS];                                   // the tasks that enter the search loop: >= 2 first hops from the front, 1 from the back
-#endif
     uint8_t big[MG_BIGSTACK];                               // (also the PACKED write-out's 32 x u16 list offsets, once the searches are done)
     uint32_t redo[MG_TASKS / 32];                           // tasks to redo on the big stack (bit per task)
 };
@@ -60,8 +49,12 @@ static_assert(MG_BIGSTACK >= 2 * MG_CHUNK, "the packed write-out keeps 32 x u16 
 // depth-first walk whose length varies a lot between checkers, so lanes do not own a fixed checker: each wave
 // takes a chunk of 32 positions = 192 (position, checker) tasks, every lane runs ONE flat state machine
 // (one visited cell per iteration: six mirror-hop lookups HOP[line pattern][position][sense], ccsp_rules.h, and a
-// stack in LDS) and pulls the next task
+// stack in a 64-bit register) and pulls the next task
 // of the chunk the moment its own is finished (ballot + rank) -- no lane waits for the longest walk of its wave.
+// Round 6 (profiles/r6_movegen_ab.txt, 5.30 -> 6.40 G states/s): the ORIGIN's six hop look-ups are made in the walk phase -- every
+// lane busy, no visited test, the three patterns already in registers -- and left as the task's initial stack image; only checkers that
+// can hop at all enter the search loop (a compacted worklist), those with two or more first hops before those with one (a wave is done
+// when its last lane is); the stack itself in a register (an LDS read and six byte-wide LDS writes off every visited cell's chain).
 // Hop landings stay on the origin's sub-lattice (row and column keep their parity: <= 4 x 4 cells), so every cell a search
 // sees has the parity of the origin's cell index (7 r + c = r + c mod 2) and cell >> 1 names it uniquely: the visited set is
 // 25 bits indexed by cell >> 1 -- one shift per test, no 64-bit shifts on a cell mask, no (row / 2, column / 2) arithmetic
@@ -114,7 +107,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     // through the origin (bits beyond a line's end are preset; the byte is stored unconditionally, kept only if legal).  Done here,
     // with every lane busy, instead of inside the search loop, where the lanes reach their origins at different iterations and the
     // whole wave would step through these ~90 instructions every time one of them does.
-    int n_two = 0, n_one = 0;                           // MG_ORIGIN_FIRST: tasks with >= 2 / exactly 1 first hop (wave-uniform)
+    int n_two = 0, n_one = 0;                           // tasks with >= 2 / exactly 1 first hop (wave-uniform)
     for (int t0 = 0; t0 < ntasks; t0 += 64) {
         const int t = t0 + lane;
         int hops0 = 0;                                  // first hops of this lane's task
@@ -130,7 +123,6 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         MG_WALK(p0, r, -1, -7) MG_WALK(p1, col, 1, 1) MG_WALK(p2, m, 1, 8) MG_WALK(p0, r, 1, 7) MG_WALK(p1, col, -1, -1) MG_WALK(p2, m, -1, -8)
 #undef MG_WALK
         L.cnt[s][c] = (uint8_t)k;
-#if MG_ORIGIN_FIRST
         // the origin's own hops (the visit the search would begin with): the checker lifted off its three lines (board.py:158), both senses of
         // each line in one 16-bit read, the landings ranked NW, W, S, SE, E, N into the register image of the stack (N on top); nothing is
         // visited yet but the origin, which no hop lands on.  The image, the count, the origin and the walk count go into bytes 8..15 of the
@@ -155,16 +147,13 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
             const uint64_t image = (((uint64_t)accA << (6 * nB)) | (uint64_t)accB) | ((uint64_t)x << 36) | ((uint64_t)k << 44) | ((uint64_t)hops0 << 48);
             *reinterpret_cast<uint64_t *>(&LST(L, s, c, 8)) = image;
         }
-#endif
         }
-#if MG_ORIGIN_FIRST
         // the worklist: tasks with two or more first hops from the front, with exactly one from the back -- the long searches start first
         // (a wave is done when its last lane is), checkers that cannot hop never enter the loop
         const uint64_t two = __ballot(hops0 >= 2), one = __ballot(hops0 == 1), below = (1ULL << lane) - 1;
         if (hops0 >= 2) L.wl[n_two + __popcll(two & below)] = (uint8_t)t;
         if (hops0 == 1) L.wl[MG_TASKS - 1 - (n_one + __popcll(one & below))] = (uint8_t)t;
         n_two += __popcll(two); n_one += __popcll(one);
-#endif
     }
     __syncthreads();
 
@@ -234,7 +223,6 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         return true;
     };
     auto finish_task = [&]() { L.cnt[st_s][st_c] = (uint8_t)cnt_n; };
-#if MG_REGSTACK
     // The same pop with the lane's stack in a REGISTER: rs = cells of 6 bits, the top in the low bits.  The six landings are ranked into two
     // 18-bit accumulators (NW, W, S | SE, E, N: first pushed = highest) and shifted in behind the popped cell in one go; the visit is
     // refused -- nothing changed -- when the stack would exceed `room` (<= 10) entries: the big-stack redo path below, as before.
@@ -243,7 +231,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     uint64_t rs = 0;
     uint8_t *const stk = nullptr;                                    // (no LDS stack: start_task leaves the origin to `rs`)
     auto step_reg = [&](int room) -> bool {
-        const int x = (int)((uint32_t)rs & 63u);
+        int x = (int)((uint32_t)rs & 63u);
         const int xi = x >> 1;
         if ((visited >> xi) & 1u) { rs >>= 6; sp--; return true; }
         const int r = (int)(__umul24((unsigned)x, 37u) >> 8), c = x - 7 * r;
@@ -279,7 +267,6 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         return true;
     };
     const int room = cap < MG_REGROOM ? cap : MG_REGROOM;
-#if MG_ORIGIN_FIRST
     const int nwork = n_two + n_one;                                 // entries of the worklist
     auto work_at = [&](int i) -> int { return (int)L.wl[i < n_two ? i : MG_TASKS - 1 - (i - n_two)]; };
     // a task starts behind its origin's visit: the stack image the walk phase left, the origin marked, the list holding the walks
@@ -298,11 +285,6 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     if (lane < nwork) { task = work_at(lane); start_work(task); active = true; }
 #define MG_NTASKS_IN_LOOP nwork
 #define MG_START(i) { task = work_at(i); start_work(task); }
-#else
-    if (task < ntasks) { start_task(task, stk); rs = (uint64_t)origin; active = true; }
-#define MG_NTASKS_IN_LOOP ntasks
-#define MG_START(i) { task = (i); start_task(task, stk); rs = (uint64_t)origin; }
-#endif
 
     while (__any(active)) {
         if (active) {
@@ -324,30 +306,6 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     }
 #undef MG_NTASKS_IN_LOOP
 #undef MG_START
-#else
-    uint8_t *stk = L.stack[lane];
-    if (task < ntasks) { start_task(task, stk); active = true; }
-
-    while (__any(active)) {
-        if (active) {
-            if (!step(stk, cap)) {                                      // does not fit: this task goes to the big stack later
-                atomicOr(&L.redo[task >> 5], 1u << (task & 31));
-                active = false;
-            } else if (sp == 0) {                                       // the search of this checker is complete
-                finish_task();
-                active = false;
-            }
-        }
-        // hand out new tasks to the lanes that just became idle
-        const uint64_t idle = __ballot(!active);
-        if (next < ntasks && idle) {
-            const int rank = __popcll(idle & ((1ULL << lane) - 1));
-            const int t = next + rank;
-            if (!active && t < ntasks) { task = t; start_task(t, stk); active = true; }
-            next += __popcll(idle);
-        }
-    }
-#endif
     // searches that did not fit a lane's stack: one at a time, lane 0, on the wave's big stack
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
