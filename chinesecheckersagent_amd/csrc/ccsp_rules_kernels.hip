@@ -9,6 +9,14 @@
 
 namespace {
 
+// diagnostic build (-DMG_STAMPS, never timed for throughput): cycles of wave 0's lane 0 of every workgroup per phase of movegen_kernel, summed
+#ifdef MG_STAMPS
+__device__ unsigned long long mg_stamps[8];
+#define MG_LAP(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&mg_stamps[i], now_ - lap_); lap_ = now_; } } while (0)
+#else
+#define MG_LAP(i) do { } while (0)
+#endif
+
 constexpr int MG_THREADS = 256;
 constexpr int MG_WAVES = MG_THREADS / 64;
 constexpr int MG_CHUNK = 32;                                // states per wave
@@ -32,6 +40,15 @@ constexpr int MG_REGROOM = 10;                              // entries of a lane
                                                             // Real positions never hold more than 8 (tests/test_device_logic_on_host.py:
                                                             // 400 000 positions); a search that would need more is redone on the wave's one
                                                             // big stack in LDS (MG_BIGSTACK)
+
+// preset (off-board) bits of the 13 diagonals' patterns, eight lines to a 64-bit word (columns and rows are seven cells long: nothing preset)
+static constexpr uint64_t mg_diag_base(int first, int count) {
+    const ccsp_line_tables t = ccsp_make_lines();
+    uint64_t v = 0;
+    for (int i = 0; i < count; i++) v |= (uint64_t)t.base[14 + first + i] << (8 * i);
+    return v;
+}
+constexpr uint64_t MG_BASE_DA = mg_diag_base(0, 8), MG_BASE_DB = mg_diag_base(8, 5);
 
 struct __attribute__((aligned(8))) MgWave {                      // per-wave LDS: 6.1 KB -> SIX 4-wave workgroups per CU (the per-lane LDS stacks of
                                                                  // rounds 2-5 made it 7.1 KB and five)
@@ -76,32 +93,65 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     __shared__ MgWave WV[MG_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     MgWave &L = WV[wave];
-    ccsp_load_lines_to_lds(&T, tid, MG_THREADS);
+#ifdef MG_STAMPS
+    unsigned long long lap_ = __builtin_amdgcn_s_memtime();
+#endif
+    // The order of a workgroup's start (round 6): the line tables' 559 dwords are REQUESTED first (three per thread, into registers), then the
+    // wave's position records; the 27 patterns of every position are built from the record alone while the table is still in flight, and only
+    // then does the table go into LDS -- one memory latency at a workgroup's start instead of two in a row (the stamps of the one-after-the-
+    // other order: 29 % + 17 % of a workgroup's lifetime, profiles/r6_movegen_ab.txt).
+    constexpr int TDW = (int)(sizeof(ccsp_line_tables) / 4), TPER = (TDW + MG_THREADS - 1) / MG_THREADS;
+    uint32_t tab[TPER];
+#pragma unroll
+    for (int i = 0; i < TPER; i++) { const int j = tid + i * MG_THREADS; tab[i] = j < TDW ? reinterpret_cast<const uint32_t *>(&CCSP_LINES_DEV)[j] : 0u; }
     const long long base = ((long long)blockIdx.x * MG_WAVES + wave) * MG_CHUNK;     // first position of this wave
     const int here = (int)((n - base) < 0 ? 0 : ((n - base) < MG_CHUNK ? (n - base) : MG_CHUNK));
     if (lane < MG_TASKS / 32) L.redo[lane] = 0;
-    __syncthreads();
+    MG_LAP(0);                                          // [0] requests issued
 
-    // ---- line patterns: lane = position -----------------------------------------------------------------
-    int my_player = 1;
+    // ---- line patterns: IN REGISTERS, half a wave per side -------------------------------------------------------
+    // A checker at (r, c) sets bit 8 c + r of the columns' word, bit 8 r + c of the rows' word and bit 8 (r - c + 6) + min(r, c) of the
+    // diagonals' two words -- shifts and ORs, no table, no chain of 36 dependent byte read-modify-writes in LDS; the lower half of the wave
+    // takes player one's six checkers of its position, the upper half player two's; the halves meet through one cross-lane exchange and the
+    // row goes to LDS as seven dwords: bytes 0-6 columns, 7-13 rows, 14-26 diagonals (ccsp_rules.h: LP / base).
     {
-        if (lane < MG_CHUNK) for (int l = 0; l < CCSP_NLINES; l++) L.lines[lane][l] = T.base[l];
-        if (lane < here) {
-            const ccsp_sr s = ccsp_load_sr(states + base + lane);
-            my_player = player[base + lane];
+        static_assert(MG_LINES_STRIDE == 28 && MG_CHUNK == 32, "a position's patterns are seven dwords; half a wave per side");
+        const int p = lane & 31, side = lane >> 5;
+        uint64_t a0 = 0, a1 = 0, da = 0, db = 0;
+        ccsp_sr s; s.occ0 = s.occ1 = s.a = s.b = 0;
+        int my_player = 1;
+        if (p < here) {
+            s = ccsp_load_sr(states + base + p);
+            my_player = player[base + p];
 #pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const int cell = ccsp_sr_pos(s, k);
-#pragma unroll
-                for (int a = 0; a < 3; a++) { const int lp = T.lp[cell][a]; L.lines[lane][lp >> 3] |= (uint8_t)(1u << (lp & 7)); }
+            for (int k = 0; k < 6; k++) {
+                const int cell = ccsp_sr_pos(s, 6 * side + k);
+                const int r = (int)(__umul24((unsigned)cell, 37u) >> 8), c = cell - 7 * r;
+                a0 |= 1ULL << (8 * c + r);
+                a1 |= 1ULL << (8 * r + c);
+                const int sh = 8 * (r - c + 6) + (r < c ? r : c);              // 0 .. 102
+                const uint64_t bit = 1ULL << (sh & 63);
+                da |= sh < 64 ? bit : 0ULL;
+                db |= sh < 64 ? 0ULL : bit;
             }
-            // stash what the tasks need: origin cells of the side to move, in the last byte of each list slot
-#pragma unroll
-            for (int c = 0; c < 6; c++) LST(L, lane, c, MG_SLOT - 1) = (uint8_t)ccsp_sr_pos(s, (my_player - 1) * 6 + c);
+        }
+        a0 |= __shfl_xor(a0, 32); a1 |= __shfl_xor(a1, 32); da |= __shfl_xor(da, 32); db |= __shfl_xor(db, 32);
+        da |= MG_BASE_DA; db |= MG_BASE_DB;
+        if (lane < here) {                                                      // (the lower half writes the rows ...)
+            uint32_t *row = reinterpret_cast<uint32_t *>(&L.lines[lane][0]);
+            const uint64_t w0 = a0 | (a1 << 56), w1 = (a1 >> 8) | (da << 48), w2 = (da >> 16) | (db << 48);
+            row[0] = (uint32_t)w0; row[1] = (uint32_t)(w0 >> 32); row[2] = (uint32_t)w1; row[3] = (uint32_t)(w1 >> 32);
+            row[4] = (uint32_t)w2; row[5] = (uint32_t)(w2 >> 32); row[6] = (uint32_t)(db >> 16);
+        } else if (side == 1 && p < here) {                                     // ... the upper half what the tasks need: the origin cells of the
+#pragma unroll                                                                  // side to move, in the last byte of each list slot
+            for (int c = 0; c < 6; c++) LST(L, p, c, MG_SLOT - 1) = (uint8_t)ccsp_sr_pos(s, (my_player - 1) * 6 + c);
         }
     }
+#pragma unroll
+    for (int i = 0; i < TPER; i++) { const int j = tid + i * MG_THREADS; if (j < TDW) reinterpret_cast<uint32_t *>(&T)[j] = tab[i]; }
     __syncthreads();
 
+    MG_LAP(1);                                          // [1] records in, line patterns, table into LDS
     const int ntasks = here * 6;
     // ---- walks: lane = task, three rounds.  Direction order N,E,SE,S,W,NW (board.py:149-155), read off the three line patterns
     // through the origin (bits beyond a line's end are preset; the byte is stored unconditionally, kept only if legal).  Done here,
@@ -157,6 +207,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     }
     __syncthreads();
 
+    MG_LAP(2);                                          // [2] walks + the origins' hops + worklist
     // ---- task loop: lane = worker ---------------------------------------------------------------------------
     // The ordered hop search (board.py:166-211) with an explicit stack: popping a cell that is still unvisited
     // visits it (= the recursive call), looks up the mirror hop in all six directions (three line patterns, two
@@ -306,6 +357,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     }
 #undef MG_NTASKS_IN_LOOP
 #undef MG_START
+    MG_LAP(3);                                          // [3] the search loop
     // searches that did not fit a lane's stack: one at a time, lane 0, on the wave's big stack
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -323,6 +375,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
     }
     __syncthreads();
 
+    MG_LAP(4);                                          // [4] big-stack redo
     // ---- destination masks (optional output): lane = task, the cells of its finished list.  (Tried instead: the walk cells
     // stored here in the walk phase and the hop cells ORed in by an atomic when a task ends -- the extra instructions in the search
     // loop cost more; LDS atomics from the write-out lanes -- one word per checker serialises them.) ---------------------------
@@ -336,6 +389,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
         }
         __syncthreads();                                // the counts are rewritten below
     }
+    MG_LAP(5);                                          // [5] destination masks
     // ---- write out in the reference's move order: half a wave per position, lane = move slot ------------------
     int my_k = 0;                                       // this position's number of moves (lane = position)
     if (lane < here) {                                  // prefix sums of the six per-checker counts, packed one byte each
@@ -428,6 +482,7 @@ __global__ __launch_bounds__(MG_THREADS) void movegen_kernel(const ccsp_state *_
             if (on && hl == 0) count[base + s] = (uint8_t)(nb < CCSP_GREEDY_MAX ? nb : CCSP_GREEDY_MAX);
         }
     }
+    MG_LAP(6);                                          // [6] write-out
 }
 
 // B5-B7: one lane per state; the record moves as two 16-byte accesses.
@@ -532,6 +587,15 @@ int ccsp_debug_movegen_stack_cap(int cap) {
     g_cap = (cap >= 6 && cap <= MG_STACK) ? cap : MG_STACK;
     return g_cap;
 }
+
+#ifdef MG_STAMPS
+int ccsp_debug_movegen_stamps(unsigned long long *out, int clear) {
+    CCSP_HIPCHK(hipDeviceSynchronize());
+    CCSP_HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(mg_stamps), sizeof(unsigned long long) * 8));
+    if (clear) { unsigned long long z[8] = {0}; CCSP_HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mg_stamps), z, sizeof(z))); }
+    return CCSP_OK;
+}
+#endif
 
 int ccsp_movegen(const ccsp_state *s, const uint8_t *player, int n, uint8_t *moves, uint8_t *count,
                  uint64_t *dest_mask, void *stream) {
