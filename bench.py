@@ -859,7 +859,7 @@ def extras(eng, G, S, torch, _lib, engine):
         sink = sp.TrainDataSink(); sink.discard = True
         run = sp.SelfPlayRun(m, n_games=G * 64, sims=S, seed=SEED, max_slots=G, keep_records=False, sink=sink, free_running=False, off_path_ok=True)
         try:
-            for _ in range(80):                            # (as many untimed plies as the headline's spread + warm-up: the same steady state)
+            for _ in range(80):                            # (untimed plies: the lock-step cohort plays in step, its expansions/s do not depend on the spread)
                 run.play_ply()
             run.drain()
             torch.cuda.synchronize()
