@@ -93,7 +93,7 @@ def net_roofline(n_pos, launch_ms, isolated_ms, wall_ms_per_launch, step_ms_per_
         'wall_ms_per_launch': wall_ms_per_launch, 'step_ms_per_launch': step_ms_per_launch,
         'launches_in_flight': own / wall_ms_per_launch,       # > 1: consecutive launches of the two half-batches overlap
         'how': ('frac = FLOP per launch / avg_launch_ms / peak; avg_launch_ms: median of %d launches inside the timed region, HIP events on the '
-                'launching stream, the other half-batch running beside them' % samples) if launch_ms else
+                'launching stream (net of the event pair\'s own cost), the other half-batch running beside them' % samples) if launch_ms else
                'frac = FLOP per launch / (wall time of the timed rounds / evaluator launches in them) / peak (no uncaptured round to put events around)',
         'launches_in_timed_region_per_gpu': launches, 'tree_kernels_ms_in_the_same_rounds': tree_ms,
         'asked_rows_in_isolated_batch': asked_rows_in_isolated_batch,
@@ -279,7 +279,19 @@ def net_kernel_alone(model, req, moves, torch):
         L.ccsp_net_forward_requests(packed.data_ptr(), req.data_ptr(), moves.data_ptr(), n_pos, pk.data_ptr(), v_out.data_ptr(), st)
     e.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(e) / iters
+    burst_ms = a.elapsed_time(e) / iters
+    # what a PAIR OF EVENTS around one launch adds to its duration (the markers are packets of their own): the same launches, still alone,
+    # each between its own two events -- the in-pipeline figure is taken the same way and is corrected by the difference
+    pairs = []
+    for _ in range(48):
+        x, y = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x.record()
+        L.ccsp_net_forward_requests(packed.data_ptr(), req.data_ptr(), moves.data_ptr(), n_pos, pk.data_ptr(), v_out.data_ptr(), st)
+        y.record()
+        pairs.append((x, y))
+    torch.cuda.synchronize()
+    br = sorted(x.elapsed_time(y) for x, y in pairs)
+    return burst_ms, max(0.0, br[len(br) // 2] - burst_ms)
 
 
 def config3(args, torch, rank, world, local, barrier):
@@ -367,8 +379,8 @@ def config3(args, torch, rank, world, local, barrier):
         req_alone = torch.from_numpy(r_.view(np.uint8).reshape(n_pos, 64)).to('cuda:%d' % local)
         moves_alone = torch.zeros((n_pos, _l.REQUEST_MOVES), dtype=torch.int16, device=req_alone.device)
         asked_now = n_pos
-    k_ms = net_kernel_alone(model, req_alone, moves_alone, torch)
-    return d, dt, dict(n_pos=n_pos, k_ms=k_ms, parts=parts, weights=os.path.basename(w) if w else 'random-init', backend=model.backend,
+    k_ms, ev_over_ms = net_kernel_alone(model, req_alone, moves_alone, torch)
+    return d, dt, dict(n_pos=n_pos, k_ms=k_ms, ev_over_ms=ev_over_ms, parts=parts, weights=os.path.basename(w) if w else 'random-init', backend=model.backend,
                        steps=steps, rows_written=int(rows), file_bytes=size, t_play=t_play, t_drain=t_drain, t_write=t_write,
                        n_slots=run.n_slots, free_running=bool(getattr(run, 'free_running', False)), asked_in_isolated_batch=asked_now,
                        net_in_pipeline_ms=(sorted(net_in_pipeline_ms)[len(net_in_pipeline_ms) // 2] if net_in_pipeline_ms else None),
@@ -580,7 +592,8 @@ def main():
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         host = [[float(x) for x in e.tolist()] for e in every]
-    k_in_local = info.get('net_in_pipeline_ms') or (info['t_play'] / (info['steps'] * (S + 1) * info['parts']) * 1e3)
+    # (the in-pipeline launches are timed between a pair of events each: the pair's own cost, measured on the same launches alone, is taken off)
+    k_in_local = (info['net_in_pipeline_ms'] - info['ev_over_ms']) if info.get('net_in_pipeline_ms') else (info['t_play'] / (info['steps'] * (S + 1) * info['parts']) * 1e3)
     k_in_all = max_over_ranks(k_in_local)
 
     out = None
@@ -650,6 +663,7 @@ def main():
                                      tree_ms=info.get('tree_in_pipeline_ms'), launches=launches,
                                      asked_rows_in_isolated_batch=info.get('asked_in_isolated_batch')),
         }
+        out['roofline']['event_pair_overhead_ms'] = info['ev_over_ms']        # taken off avg_launch_ms (raw median: + this)
         try:                                 # HBM bytes of one launch by the counters (static: a --pmc pass cannot run inside this process)
             prof = json.load(open(os.path.join(ROOT, 'profiles', 'counters.json')))['net_forward_kernel']
             if info['n_pos'] == prof['n']:
