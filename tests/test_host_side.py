@@ -385,3 +385,13 @@ def test_bench_roofline_arithmetic_on_canned_numbers():
     # no uncaptured round to put events around: the wall time per launch stands in, and the record says so
     r2 = bench.net_roofline(2048, None, 0.10429, 0.11196, 0.11365, 17.11e6)
     assert r2['frac'] == r2['frac_by_wall'] and r2['avg_launch_ms'] == 0.11196 and 'wall time' in r2['how']
+
+
+def test_small_cohort_rank_policy():
+    """selfplay.selfplay_ranks: a cohort of fewer than 256 games per rank is latency-bound (profiles/r6_small_cohort.txt: 180 games x 800
+    simulations take 6.52 s in 180 slots of one GPU, 5.91 s as one of eight ranks' 23), so min(R, ceil(games / 256)) ranks play it"""
+    from chinesecheckersagent_amd import selfplay as sp
+    assert sp.MIN_GAMES_PER_RANK == 256
+    assert [sp.selfplay_ranks(n, 8) for n in (1, 180, 256, 257, 512, 1024, 2047, 2048, 32768)] == [1, 1, 1, 2, 2, 4, 8, 8, 8]
+    assert sp.selfplay_ranks(180, 1) == 1 and sp.selfplay_ranks(0, 8) == 1
+    assert sp.selfplay_ranks(9, 2, min_games_per_rank=1) == 2 and sp.selfplay_ranks(40, 5, min_games_per_rank=16) == 3
