@@ -1824,8 +1824,8 @@ __global__ __launch_bounds__(64, 4) void boundary_kernel(Params P, const double 
     const uint64_t w15 = uni64(P.slots[g].w[15]);
     uint32_t phase = (uint32_t)(w15 & 0xFF), half = (uint32_t)((w15 >> 8) & 1), root_shadow = (uint32_t)(w15 >> 32), fin = (uint32_t)((w15 >> 10) & 3);
     if (phase == 1) return;                               // in a search: advance_kernel's business
-    // a root request of THIS context is outstanding (bit 12 of word 15): only then does the record's kind mean anything -- the request
-    // buffer is the caller's, and what it holds after a ccsp_reset / ccsp_set_positions is not to be trusted
+    // a root request of this slot is outstanding (bit 12 of word 15): only then does its record's kind mean anything -- ccsp_set_positions
+    // starts the slots over without touching the records, and what a record holds from an earlier run is not to be taken up
     const bool asked = ((w15 >> 12) & 1) != 0;
     // THE HAND-OFF STATE IS THE ENGINE'S OWN (P.pend): kind, k, and in advance_kernel depth / link / the walk to resume are read from the
     // context's record, never from the caller's buffer -- `req` is an OUTPUT (position, kind, player, k: what an evaluator reads), so a
